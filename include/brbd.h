@@ -1,0 +1,179 @@
+/*
+ * brbd.h -- C ABI of the MI355X batched rigid-body-dynamics engine
+ * (libbrbd_hip.so).  This is the drop-in boundary for the data-parallel path
+ * of Pinocchio: everything under the `#pragma omp parallel for` of
+ *   include/pinocchio/algorithm/parallel/rnea.hpp:74-82
+ *   include/pinocchio/algorithm/parallel/aba.hpp:75-83
+ * plus batched forwardKinematics / computeJointJacobians / computeRNEADerivatives.
+ *
+ * Plain pointers and sizes only; no torch / Eigen / STL types cross this line.
+ * Every function returns BRBD_OK (0) or a negative status and never throws;
+ * brbd_last_error() returns a thread-local message for the last failure.
+ *
+ * Conventions (identical to the reference):
+ *   - spatial vectors are [linear(3); angular(3)]
+ *     (multibody/joint/joint-revolute.hpp:56-60)
+ *   - free-flyer q = [x y z, qx qy qz qw], v = [v_lin_body, w_body]
+ *     (multibody/joint/joint-free-flyer.hpp:259-282); quaternions are NOT
+ *     normalised by the engine (joint-free-flyer.hpp:338-339)
+ *   - all arithmetic is IEEE fp64
+ */
+#ifndef BRBD_H
+#define BRBD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes ------------------------------------------------------ */
+#define BRBD_OK 0
+#define BRBD_ERR_INVALID_ARGUMENT (-1) /* reference: std::invalid_argument       */
+#define BRBD_ERR_UNSUPPORTED (-2)      /* joint type outside the supported set   */
+#define BRBD_ERR_RUNTIME (-3)          /* HIP failure (reference: n/a)           */
+#define BRBD_ERR_NO_DEVICE (-4)        /* no HIP device / extension not usable   */
+
+/* ---- joint kinds (JointModelVariant alternatives,
+ *      multibody/joint/joint-collection.hpp:86-112) ----------------------- */
+enum brbd_joint_type {
+  BRBD_JOINT_RX = 0, /* JointModelRX  joint-revolute.hpp   */
+  BRBD_JOINT_RY = 1,
+  BRBD_JOINT_RZ = 2,
+  BRBD_JOINT_PX = 3, /* JointModelPX  joint-prismatic.hpp  */
+  BRBD_JOINT_PY = 4,
+  BRBD_JOINT_PZ = 5,
+  BRBD_JOINT_FREEFLYER = 6,          /* joint-free-flyer.hpp              */
+  BRBD_JOINT_SPHERICAL = 7,          /* joint-spherical.hpp               */
+  BRBD_JOINT_REVOLUTE_UNALIGNED = 8, /* joint-revolute-unaligned.hpp      */
+  BRBD_JOINT_PRISMATIC_UNALIGNED = 9,
+  BRBD_JOINT_RUBX = 10, /* JointModelRUBX joint-revolute-unbounded.hpp (nq=2: cos,sin) */
+  BRBD_JOINT_RUBY = 11,
+  BRBD_JOINT_RUBZ = 12,
+  BRBD_JOINT_TYPE_COUNT = 13
+};
+
+/* ---- matrix layout at the boundary ------------------------------------- */
+enum brbd_layout {
+  /* Pinocchio / Eigen column-major (dof x B): element (d, b) at x[b*ld + d],
+   * ld >= dof.  This is what rneaInParallel receives
+   * (algorithm/parallel/rnea.hpp:39-45). */
+  BRBD_INSTANCE_MAJOR = 0,
+  /* Engine-native SoA: element (d, b) at x[d*ld + b], ld >= B.  The batch is
+   * the fastest-varying dimension so one lane per instance coalesces. */
+  BRBD_BATCH_MAJOR = 1
+};
+
+enum brbd_memspace {
+  BRBD_HOST = 0,  /* pointers are host memory: the call stages H2D/D2H itself */
+  BRBD_DEVICE = 1 /* pointers are device memory on the model's device         */
+};
+
+/* ---- constant model description ---------------------------------------
+ * Mirrors the ModelTpl fields the hot path reads (multibody/model.hpp:107-132,
+ * 154,176,248).  Joint 0 is the universe; entries [0] of the per-joint arrays
+ * are ignored.  parents[i] < i must hold (multibody/model.hxx:144-151). */
+typedef struct brbd_model_desc {
+  int32_t njoints; /* model.njoints (universe included)                      */
+  int32_t nq;      /* model.nq                                               */
+  int32_t nv;      /* model.nv                                               */
+  const int32_t* parents; /* [njoints]  model.parents                        */
+  const int32_t* jtype;   /* [njoints]  enum brbd_joint_type                 */
+  const int32_t* idx_q;   /* [njoints]  model.idx_qs                         */
+  const int32_t* idx_v;   /* [njoints]  model.idx_vs                         */
+  /* [njoints][12] model.jointPlacements: rotation COLUMN-major (Eigen Matrix3
+   * memory order) in [0..8], translation in [9..11]                         */
+  const double* placement;
+  /* [njoints][10] model.inertias: mass, lever c[3], Symmetric3 data
+   * (xx,xy,yy,xz,yz,zz) of the rotational inertia about the COM
+   * (spatial/inertia.hpp:286-291, spatial/symmetric3.hpp:43-52)             */
+  const double* inertia;
+  /* [njoints][3] unit axis for *_UNALIGNED joints, ignored otherwise; may be
+   * NULL when the model has no unaligned joint                              */
+  const double* axis;
+  const double* armature; /* [nv] model.armature; NULL = zeros               */
+  double gravity[3];      /* model.gravity.linear(), default (0,0,-9.81)     */
+} brbd_model_desc;
+
+typedef struct brbd_model brbd_model; /* opaque: flattened BatchModel + device table */
+
+/* Last error message of the calling thread ("" if none). */
+const char* brbd_last_error(void);
+
+/* Library / device probes (never touch the GPU before brbd_model_create). */
+const char* brbd_version(void);
+int brbd_device_count(void);
+
+/* Flatten a model description into the device-constant BatchModel table on
+ * HIP device `device` (replaces one ModelPoolTpl replica set,
+ * multibody/pool/model.hpp:41-46).  Rejects unsupported joint types with
+ * BRBD_ERR_UNSUPPORTED, malformed tables with BRBD_ERR_INVALID_ARGUMENT. */
+int brbd_model_create(const brbd_model_desc* desc, int device, brbd_model** out);
+int brbd_model_destroy(brbd_model* m);
+int brbd_model_dims(const brbd_model* m, int32_t* njoints, int32_t* nq, int32_t* nv);
+
+/* Bytes of device workspace the kernels spill to for a batch of B instances
+ * (reported separately from algorithmic I/O in the roofline). */
+int64_t brbd_workspace_bytes(const brbd_model* m, int algo, int64_t B);
+enum brbd_algo { BRBD_ALGO_RNEA = 0, BRBD_ALGO_ABA = 1, BRBD_ALGO_FK_JAC = 2, BRBD_ALGO_RNEA_DERIV = 3 };
+
+/* tau = RNEA(q, v, a) for B instances.
+ * Replaces the loop body of rneaInParallel (algorithm/parallel/rnea.hpp:74-82)
+ * = impl::rnea (algorithm/rnea.hxx:117-161).
+ * `stream` is a hipStream_t (NULL = default stream).  With BRBD_DEVICE the call
+ * is asynchronous on `stream`; with BRBD_HOST it returns after the results are
+ * in `tau`. */
+int brbd_rnea(brbd_model* m, int64_t B, const double* q, int64_t ldq, const double* v, int64_t ldv,
+              const double* a, int64_t lda, double* tau, int64_t ldtau, int layout, int memspace,
+              void* stream);
+
+/* ddq = ABA(q, v, tau), WORLD convention, for B instances.
+ * Replaces the loop body of abaInParallel (algorithm/parallel/aba.hpp:75-83)
+ * = impl::abaWorldConvention (algorithm/aba.hxx:243-294). */
+int brbd_aba(brbd_model* m, int64_t B, const double* q, int64_t ldq, const double* v, int64_t ldv,
+             const double* tau, int64_t ldtau, double* ddq, int64_t ldddq, int layout, int memspace,
+             void* stream);
+
+/* forwardKinematics(q) + computeJointJacobians(q) for B instances
+ * (algorithm/kinematics.hxx:52-97, algorithm/jacobian.hxx:38-95).
+ * J: per instance 6 x nv column-major (row 0-2 linear, 3-5 angular), WORLD
+ *    frame; element (r, c) of instance b is
+ *      INSTANCE_MAJOR: J[b*ldJ + c*6 + r]   (ldJ >= 6*nv)
+ *      BATCH_MAJOR:    J[(c*6 + r)*ldJ + b] (ldJ >= B)
+ * oMi: per instance njoints x 12 (rotation column-major then translation),
+ *    joint 0 = identity; same two layouts with dof = 12*njoints.
+ * Either of J / oMi may be NULL to skip that output. */
+int brbd_fk_jacobians(brbd_model* m, int64_t B, const double* q, int64_t ldq, double* J, int64_t ldJ,
+                      double* oMi, int64_t ldoMi, int layout, int memspace, void* stream);
+
+/* computeRNEADerivatives (algorithm/rnea-derivatives.hxx:472-541) for B
+ * instances.  Each output is nv x nv column-major per instance (element (r,c)
+ * at offset c*nv + r), in the two layouts above with dof = nv*nv.  Unlike the
+ * reference (rnea-derivatives.hpp:104-106) the outputs need not be pre-zeroed:
+ * the engine writes every element (structural zeros included); dtau_da holds
+ * the UPPER triangle of M like the reference, strictly-lower part zero.
+ * dtau_da and tau may be NULL. */
+int brbd_rnea_derivatives(brbd_model* m, int64_t B, const double* q, int64_t ldq, const double* v,
+                          int64_t ldv, const double* a, int64_t lda, double* dtau_dq, int64_t lddq,
+                          double* dtau_dv, int64_t lddv, double* dtau_da, int64_t ldda, double* tau,
+                          int64_t ldtau, int layout, int memspace, void* stream);
+
+/* Layout helpers (device): instance-major <-> batch-major transposes used by
+ * the INSTANCE_MAJOR entry points; exposed for harnesses.
+ * dst/src are device pointers; dof x B logical matrix. */
+int brbd_transpose_to_batch_major(int device, int64_t dof, int64_t B, const double* src, int64_t ld_src,
+                                  double* dst, int64_t ld_dst, void* stream);
+int brbd_transpose_to_instance_major(int device, int64_t dof, int64_t B, const double* src,
+                                     int64_t ld_src, double* dst, int64_t ld_dst, void* stream);
+
+/* Average device time (ms) of the last kernel launch of `algo` on this model,
+ * measured with hipEvents on the launch stream when timing is enabled with
+ * brbd_set_timing(m, 1).  Used by bench.py for the roofline. */
+int brbd_set_timing(brbd_model* m, int enabled);
+int brbd_last_kernel_ms(brbd_model* m, int algo, double* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BRBD_H */

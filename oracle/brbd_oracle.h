@@ -1,0 +1,64 @@
+/*
+ * brbd_oracle.h -- CPU restatement of Pinocchio's rnea / aba / forwardKinematics
+ * / computeJointJacobians / computeRNEADerivatives for ONE instance, plus
+ * OpenMP batch loops shaped like rneaInParallel / abaInParallel.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may call this.  The product (libbrbd_hip.so)
+ * never links or loads it.
+ *
+ * PARITY UNPINNED BY VALUE: the reference cannot be compiled or imported in
+ * the build container (needs Eigen, Boost, urdfdom) and holds
+ * no golden numbers for this path.  This restatement is
+ * pinned by (1) the reference's own test invariants re-expressed in
+ * tests/test_oracle_invariants.py and (2) agreement <= 1e-12 with the
+ * structurally independent numpy implementation in oracle/naive_np.py.
+ */
+#ifndef BRBD_ORACLE_H
+#define BRBD_ORACLE_H
+
+#include "../include/brbd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* all q/v/a/tau pointers: one instance, contiguous (nq or nv doubles) */
+
+/* algorithm/rnea.hxx:117-161 */
+int brbd_oracle_rnea(const brbd_model_desc* m, const double* q, const double* v, const double* a,
+                     double* tau);
+/* algorithm/aba.hxx:243-294 (WORLD; what abaInParallel calls, parallel/aba.hpp:82) */
+int brbd_oracle_aba_world(const brbd_model_desc* m, const double* q, const double* v,
+                          const double* tau, double* ddq);
+/* algorithm/aba.hxx:488-542 (LOCAL; cross-check, unittest/aba.cpp:157-159) */
+int brbd_oracle_aba_local(const brbd_model_desc* m, const double* q, const double* v,
+                          const double* tau, double* ddq);
+/* algorithm/kinematics.hxx:52-97 + algorithm/jacobian.hxx:38-95.
+ * J: 6 x nv column-major (may be NULL); oMi: njoints x 12, rotation column-major
+ * then translation (may be NULL). */
+int brbd_oracle_fk_jacobians(const brbd_model_desc* m, const double* q, double* J, double* oMi);
+/* algorithm/rnea-derivatives.hxx:472-541.  Outputs nv x nv column-major, fully
+ * written (zeros included); dtau_da upper triangle only.  dtau_da / tau may be NULL. */
+int brbd_oracle_rnea_derivatives(const brbd_model_desc* m, const double* q, const double* v,
+                                 const double* a, double* dtau_dq, double* dtau_dv, double* dtau_da,
+                                 double* tau);
+
+/* Batch loops: `#pragma omp parallel for schedule(static)` over instance-major
+ * columns with per-thread scratch, as algorithm/parallel/rnea.hpp:70-82.
+ * num_threads <= 0 means omp_get_max_threads(). Returns threads used or <0. */
+int brbd_oracle_rnea_batch(const brbd_model_desc* m, int64_t B, const double* q, const double* v,
+                           const double* a, double* tau, int num_threads);
+int brbd_oracle_aba_batch(const brbd_model_desc* m, int64_t B, const double* q, const double* v,
+                          const double* tau, double* ddq, int num_threads);
+int brbd_oracle_fk_jacobians_batch(const brbd_model_desc* m, int64_t B, const double* q, double* J,
+                                   double* oMi, int num_threads);
+int brbd_oracle_rnea_derivatives_batch(const brbd_model_desc* m, int64_t B, const double* q,
+                                       const double* v, const double* a, double* dq, double* dv,
+                                       double* da, double* tau, int num_threads);
+int brbd_oracle_max_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

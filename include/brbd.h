@@ -152,7 +152,8 @@ int brbd_fk_jacobians(brbd_model* m, int64_t B, const double* q, int64_t ldq, do
  * at offset c*nv + r), in the two layouts above with dof = nv*nv.  Unlike the
  * reference (rnea-derivatives.hpp:104-106) the outputs need not be pre-zeroed:
  * the engine writes every element (structural zeros included); dtau_da holds
- * the UPPER triangle of M like the reference, strictly-lower part zero.
+ * the UPPER triangle of M like the reference (plus the full nvj x nvj diagonal
+ * block of multi-dof joints, as rnea-derivatives.hxx:420-421 writes it).
  * dtau_da and tau may be NULL. */
 int brbd_rnea_derivatives(brbd_model* m, int64_t B, const double* q, int64_t ldq, const double* v,
                           int64_t ldv, const double* a, int64_t lda, double* dtau_dq, int64_t lddq,
@@ -167,11 +168,12 @@ int brbd_transpose_to_batch_major(int device, int64_t dof, int64_t B, const doub
 int brbd_transpose_to_instance_major(int device, int64_t dof, int64_t B, const double* src,
                                      int64_t ld_src, double* dst, int64_t ld_dst, void* stream);
 
-/* Average device time (ms) of the last kernel launch of `algo` on this model,
- * measured with hipEvents on the launch stream when timing is enabled with
- * brbd_set_timing(m, 1).  Used by bench.py for the roofline. */
+/* Kernel timing for the roofline (bench.py): with timing enabled every kernel launch of the
+ * engine is bracketed by hipEvents recorded on the launch stream.  brbd_kernel_time() waits for
+ * the recorded launches of `algo` (enum brbd_algo), returns how many there were and their summed
+ * device time in milliseconds, and forgets them. */
 int brbd_set_timing(brbd_model* m, int enabled);
-int brbd_last_kernel_ms(brbd_model* m, int algo, double* ms);
+int brbd_kernel_time(brbd_model* m, int algo, int32_t* launches, double* total_ms);
 
 #ifdef __cplusplus
 }

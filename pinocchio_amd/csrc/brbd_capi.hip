@@ -1,0 +1,566 @@
+// brbd_capi.hip -- C ABI (include/brbd.h) of the MI355X batched rigid-body-dynamics engine.
+//
+// Host side of the drop-in boundary: argument validation with the reference's error behaviour
+// (algorithm/parallel/rnea.hpp:53-68, parallel/aba.hpp:54-69 -> std::invalid_argument, here
+// BRBD_ERR_INVALID_ARGUMENT), the BatchModel flattener, workspace ownership and kernel launches.
+// There is NO CPU fallback in this library: without a HIP device every compute entry point
+// fails with BRBD_ERR_NO_DEVICE / BRBD_ERR_RUNTIME.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/brbd.h"
+#include "brbd_flatten.hpp"
+#include "brbd_kernels.hpp"
+#include "brbd_deriv.hpp"
+
+using namespace brbd;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                       \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess)                                                                   \
+      return fail(BRBD_ERR_RUNTIME, std::string(#expr) + ": " + hipGetErrorString(e_));     \
+  } while (0)
+
+struct TimedLaunch {
+  hipEvent_t start, stop;
+};
+
+}  // namespace
+
+struct brbd_model {
+  FlatModel flat;
+  int device = 0;
+  int num_cu = 0;
+  JointConst* d_tab = nullptr;
+  Op* d_prog = nullptr;
+  Op* d_prog3 = nullptr;
+  int* d_nvsub = nullptr;
+  double* d_ws = nullptr;
+  size_t ws_doubles = 0;
+  // host-memspace staging
+  double* d_stage = nullptr;
+  size_t stage_doubles = 0;
+  // per-algorithm launch geometry (waves resident on the device)
+  int max_waves[4] = {0, 0, 0, 0};
+  bool timing = false;
+  std::vector<TimedLaunch> timed[4];
+  std::mutex mu;
+};
+
+namespace {
+
+int ensure_ws(brbd_model* m, size_t doubles) {
+  if (doubles <= m->ws_doubles) return BRBD_OK;
+  if (m->d_ws) HIP_TRY(hipFree(m->d_ws));
+  m->d_ws = nullptr;
+  m->ws_doubles = 0;
+  HIP_TRY(hipMalloc(&m->d_ws, doubles * sizeof(double)));
+  m->ws_doubles = doubles;
+  return BRBD_OK;
+}
+
+int ensure_stage(brbd_model* m, size_t doubles) {
+  if (doubles <= m->stage_doubles) return BRBD_OK;
+  if (m->d_stage) HIP_TRY(hipFree(m->d_stage));
+  m->d_stage = nullptr;
+  m->stage_doubles = 0;
+  HIP_TRY(hipMalloc(&m->d_stage, doubles * sizeof(double)));
+  m->stage_doubles = doubles;
+  return BRBD_OK;
+}
+
+template <typename K>
+int resident_waves(brbd_model* m, K kernel, int block) {
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, 0) != hipSuccess || per_cu < 1)
+    per_cu = 4;
+  if (per_cu > 32) per_cu = 32;
+  return per_cu * m->num_cu;
+}
+
+// Validate one dof x B matrix argument against the layout (reference: row/col checks,
+// algorithm/parallel/rnea.hpp:61-68).
+int check_mat(const char* name, const void* p, int64_t ld, int64_t dof, int64_t B, int layout) {
+  if (!p) return fail(BRBD_ERR_INVALID_ARGUMENT, std::string(name) + " is NULL");
+  const int64_t need = layout == BRBD_BATCH_MAJOR ? B : dof;
+  if (ld < need)
+    return fail(BRBD_ERR_INVALID_ARGUMENT, std::string("leading dimension of ") + name + " is " +
+                                               std::to_string(ld) + ", needs >= " + std::to_string(need));
+  return BRBD_OK;
+}
+
+int check_common(brbd_model* m, int64_t B, int layout, int memspace) {
+  if (!m) return fail(BRBD_ERR_INVALID_ARGUMENT, "model handle is NULL");
+  if (B < 0) return fail(BRBD_ERR_INVALID_ARGUMENT, "batch size is negative");
+  if (layout != BRBD_INSTANCE_MAJOR && layout != BRBD_BATCH_MAJOR)
+    return fail(BRBD_ERR_INVALID_ARGUMENT, "layout must be BRBD_INSTANCE_MAJOR or BRBD_BATCH_MAJOR");
+  if (memspace != BRBD_HOST && memspace != BRBD_DEVICE)
+    return fail(BRBD_ERR_INVALID_ARGUMENT, "memspace must be BRBD_HOST or BRBD_DEVICE");
+  return BRBD_OK;
+}
+
+size_t mat_span(int64_t ld, int64_t dof, int64_t B, int layout) {
+  return (size_t)(layout == BRBD_BATCH_MAJOR ? ld * dof : ld * B);
+}
+
+void fill_common(const brbd_model* m, KArgs& A, int64_t B) {
+  const FlatModel& F = m->flat;
+  A.tab = m->d_tab;
+  A.prog = m->d_prog;
+  A.prog3 = m->d_prog3;
+  A.nops = (int)F.prog.size();
+  A.nops3 = (int)F.prog3.size();
+  A.njoints = F.njoints;
+  A.nq = F.nq;
+  A.nv = F.nv;
+  A.maxdepth = F.maxdepth;
+  A.maxbranch = F.maxbranch;
+  A.B = B;
+  A.ntiles = (B + WAVE - 1) / WAVE;
+  A.gx = F.gravity[0];
+  A.gy = F.gravity[1];
+  A.gz = F.gravity[2];
+}
+
+struct Timer {
+  brbd_model* m;
+  int algo;
+  hipStream_t s;
+  TimedLaunch t{};
+  bool on = false;
+  int begin() {
+    if (!m->timing) return BRBD_OK;
+    HIP_TRY(hipEventCreate(&t.start));
+    HIP_TRY(hipEventCreate(&t.stop));
+    HIP_TRY(hipEventRecord(t.start, s));
+    on = true;
+    return BRBD_OK;
+  }
+  int end() {
+    if (!on) return BRBD_OK;
+    HIP_TRY(hipEventRecord(t.stop, s));
+    std::lock_guard<std::mutex> g(m->mu);
+    m->timed[algo].push_back(t);
+    return BRBD_OK;
+  }
+};
+
+// One algorithm launch on device pointers.
+int launch_algo(brbd_model* m, int algo, KArgs& A, int layout, hipStream_t stream) {
+  const FlatModel& F = m->flat;
+  if (A.B == 0) return BRBD_OK;
+  int per_lane = 0;
+  switch (algo) {
+    case BRBD_ALGO_RNEA: per_lane = F.ws_rnea(); break;
+    case BRBD_ALGO_ABA: per_lane = F.ws_aba(); break;
+    case BRBD_ALGO_FK_JAC: per_lane = F.ws_fkjac(); break;
+    default: return fail(BRBD_ERR_INVALID_ARGUMENT, "unknown algorithm");
+  }
+  if (m->max_waves[algo] == 0) {
+    int w = 0;
+    if (algo == BRBD_ALGO_RNEA) w = resident_waves(m, rnea_kernel<1>, WAVE);
+    else if (algo == BRBD_ALGO_ABA) w = resident_waves(m, aba_kernel<1>, WAVE);
+    else w = resident_waves(m, fkjac_kernel<1>, WAVE);
+    m->max_waves[algo] = w;
+  }
+  int64_t grid = A.ntiles < m->max_waves[algo] ? A.ntiles : m->max_waves[algo];
+  A.ws_stride = (int64_t)per_lane * WAVE;
+  int rc = ensure_ws(m, (size_t)grid * A.ws_stride);
+  if (rc) return rc;
+  A.ws = m->d_ws;
+  Timer tm{m, algo, stream};
+  if ((rc = tm.begin())) return rc;
+  const dim3 g((unsigned)grid), b(WAVE);
+  if (algo == BRBD_ALGO_RNEA) {
+    if (layout == BRBD_BATCH_MAJOR) hipLaunchKernelGGL(rnea_kernel<1>, g, b, 0, stream, A);
+    else hipLaunchKernelGGL(rnea_kernel<0>, g, b, 0, stream, A);
+  } else if (algo == BRBD_ALGO_ABA) {
+    if (layout == BRBD_BATCH_MAJOR) hipLaunchKernelGGL(aba_kernel<1>, g, b, 0, stream, A);
+    else hipLaunchKernelGGL(aba_kernel<0>, g, b, 0, stream, A);
+  } else {
+    if (layout == BRBD_BATCH_MAJOR) hipLaunchKernelGGL(fkjac_kernel<1>, g, b, 0, stream, A);
+    else hipLaunchKernelGGL(fkjac_kernel<0>, g, b, 0, stream, A);
+  }
+  HIP_TRY(hipGetLastError());
+  return tm.end();
+}
+
+struct DevGuard {
+  int prev = -1;
+  bool ok = false;
+  explicit DevGuard(int dev) {
+    if (hipGetDevice(&prev) == hipSuccess && hipSetDevice(dev) == hipSuccess) ok = true;
+  }
+  ~DevGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
+const char* brbd_last_error(void) { return g_err.c_str(); }
+
+const char* brbd_version(void) { return "brbd 0.1 (gfx950, hip)"; }
+
+int brbd_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int brbd_model_create(const brbd_model_desc* desc, int device, brbd_model** out) {
+  if (!out) return fail(BRBD_ERR_INVALID_ARGUMENT, "out is NULL");
+  *out = nullptr;
+  FlatModel F;
+  int status = BRBD_OK;
+  const std::string err = flatten(desc, &F, &status);
+  if (status != BRBD_OK) return fail(status, err);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(BRBD_ERR_NO_DEVICE, "no HIP device available: the engine has no CPU fallback");
+  if (device < 0 || device >= ndev)
+    return fail(BRBD_ERR_INVALID_ARGUMENT, "device index " + std::to_string(device) + " out of range");
+  DevGuard dg(device);
+  if (!dg.ok) return fail(BRBD_ERR_RUNTIME, "hipSetDevice failed");
+  brbd_model* m = new brbd_model();
+  m->flat = F;
+  m->device = device;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) {
+    delete m;
+    return fail(BRBD_ERR_RUNTIME, "hipGetDeviceProperties failed");
+  }
+  m->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  auto upload = [&](void** dst, const void* src, size_t bytes) -> hipError_t {
+    hipError_t e = hipMalloc(dst, bytes ? bytes : 16);
+    if (e != hipSuccess) return e;
+    return bytes ? hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) : hipSuccess;
+  };
+  hipError_t e = upload((void**)&m->d_tab, m->flat.tab.data(), m->flat.tab.size() * sizeof(JointConst));
+  if (e == hipSuccess) e = upload((void**)&m->d_prog, m->flat.prog.data(), m->flat.prog.size() * sizeof(Op));
+  if (e == hipSuccess) e = upload((void**)&m->d_prog3, m->flat.prog3.data(), m->flat.prog3.size() * sizeof(Op));
+  if (e == hipSuccess)
+    e = upload((void**)&m->d_nvsub, m->flat.nv_subtree.data(), m->flat.nv_subtree.size() * sizeof(int));
+  if (e != hipSuccess) {
+    brbd_model_destroy(m);
+    return fail(BRBD_ERR_RUNTIME, std::string("uploading the model table: ") + hipGetErrorString(e));
+  }
+  *out = m;
+  return BRBD_OK;
+}
+
+int brbd_model_destroy(brbd_model* m) {
+  if (!m) return BRBD_OK;
+  DevGuard dg(m->device);
+  for (auto& v : m->timed)
+    for (auto& t : v) {
+      (void)hipEventDestroy(t.start);
+      (void)hipEventDestroy(t.stop);
+    }
+  if (m->d_tab) (void)hipFree(m->d_tab);
+  if (m->d_prog) (void)hipFree(m->d_prog);
+  if (m->d_prog3) (void)hipFree(m->d_prog3);
+  if (m->d_nvsub) (void)hipFree(m->d_nvsub);
+  if (m->d_ws) (void)hipFree(m->d_ws);
+  if (m->d_stage) (void)hipFree(m->d_stage);
+  delete m;
+  return BRBD_OK;
+}
+
+int brbd_model_dims(const brbd_model* m, int32_t* njoints, int32_t* nq, int32_t* nv) {
+  if (!m) return fail(BRBD_ERR_INVALID_ARGUMENT, "model handle is NULL");
+  if (njoints) *njoints = m->flat.njoints;
+  if (nq) *nq = m->flat.nq;
+  if (nv) *nv = m->flat.nv;
+  return BRBD_OK;
+}
+
+int64_t brbd_workspace_bytes(const brbd_model* m, int algo, int64_t B) {
+  if (!m || B < 0) return -1;
+  const FlatModel& F = m->flat;
+  int per_lane = 0;
+  switch (algo) {
+    case BRBD_ALGO_RNEA: per_lane = F.ws_rnea(); break;
+    case BRBD_ALGO_ABA: per_lane = F.ws_aba(); break;
+    case BRBD_ALGO_FK_JAC: per_lane = F.ws_fkjac(); break;
+    case BRBD_ALGO_RNEA_DERIV: per_lane = deriv_ws_per_lane(F); break;
+    default: return -1;
+  }
+  const int64_t tiles = (B + WAVE - 1) / WAVE;
+  return tiles * WAVE * (int64_t)per_lane * 8;
+}
+
+// ---- host-memspace plumbing: stage through one device buffer, same kernels ------------------
+namespace {
+struct Staged {
+  brbd_model* m;
+  hipStream_t stream;
+  size_t used = 0;
+  double* take(size_t doubles) {
+    double* p = m->d_stage + used;
+    used += (doubles + 31) & ~size_t(31);
+    return p;
+  }
+};
+size_t padded(size_t doubles) { return (doubles + 31) & ~size_t(31); }
+}  // namespace
+
+int brbd_rnea(brbd_model* m, int64_t B, const double* q, int64_t ldq, const double* v, int64_t ldv,
+              const double* a, int64_t lda, double* tau, int64_t ldtau, int layout, int memspace,
+              void* stream) {
+  int rc = check_common(m, B, layout, memspace);
+  if (rc) return rc;
+  const FlatModel& F = m->flat;
+  if ((rc = check_mat("q", q, ldq, F.nq, B, layout))) return rc;
+  if ((rc = check_mat("v", v, ldv, F.nv, B, layout))) return rc;
+  if ((rc = check_mat("a", a, lda, F.nv, B, layout))) return rc;
+  if ((rc = check_mat("tau", tau, ldtau, F.nv, B, layout))) return rc;
+  if (B == 0) return BRBD_OK;
+  DevGuard dg(m->device);
+  if (!dg.ok) return fail(BRBD_ERR_RUNTIME, "hipSetDevice failed");
+  hipStream_t s = (hipStream_t)stream;
+  KArgs A{};
+  fill_common(m, A, B);
+  if (memspace == BRBD_DEVICE) {
+    A.q = q; A.ldq = ldq; A.v = v; A.ldv = ldv; A.a = a; A.lda = lda; A.out = tau; A.ldout = ldtau;
+    return launch_algo(m, BRBD_ALGO_RNEA, A, layout, s);
+  }
+  const size_t nq_ = mat_span(ldq, F.nq, B, layout), nv_ = mat_span(ldv, F.nv, B, layout),
+               na_ = mat_span(lda, F.nv, B, layout), nt_ = mat_span(ldtau, F.nv, B, layout);
+  if ((rc = ensure_stage(m, padded(nq_) + padded(nv_) + padded(na_) + padded(nt_)))) return rc;
+  Staged st{m, s};
+  double *dq = st.take(nq_), *dv = st.take(nv_), *da = st.take(na_), *dt = st.take(nt_);
+  HIP_TRY(hipMemcpyAsync(dq, q, nq_ * 8, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(dv, v, nv_ * 8, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(da, a, na_ * 8, hipMemcpyHostToDevice, s));
+  if (ldtau != (layout == BRBD_BATCH_MAJOR ? B : F.nv))  // keep caller padding intact
+    HIP_TRY(hipMemcpyAsync(dt, tau, nt_ * 8, hipMemcpyHostToDevice, s));
+  A.q = dq; A.ldq = ldq; A.v = dv; A.ldv = ldv; A.a = da; A.lda = lda; A.out = dt; A.ldout = ldtau;
+  if ((rc = launch_algo(m, BRBD_ALGO_RNEA, A, layout, s))) return rc;
+  HIP_TRY(hipMemcpyAsync(tau, dt, nt_ * 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return BRBD_OK;
+}
+
+int brbd_aba(brbd_model* m, int64_t B, const double* q, int64_t ldq, const double* v, int64_t ldv,
+             const double* tau, int64_t ldtau, double* ddq, int64_t ldddq, int layout, int memspace,
+             void* stream) {
+  int rc = check_common(m, B, layout, memspace);
+  if (rc) return rc;
+  const FlatModel& F = m->flat;
+  if ((rc = check_mat("q", q, ldq, F.nq, B, layout))) return rc;
+  if ((rc = check_mat("v", v, ldv, F.nv, B, layout))) return rc;
+  // the reference forgets this check (algorithm/parallel/aba.hpp:62-69 tests `a` only); we add it
+  if ((rc = check_mat("tau", tau, ldtau, F.nv, B, layout))) return rc;
+  if ((rc = check_mat("a", ddq, ldddq, F.nv, B, layout))) return rc;
+  if (B == 0) return BRBD_OK;
+  DevGuard dg(m->device);
+  if (!dg.ok) return fail(BRBD_ERR_RUNTIME, "hipSetDevice failed");
+  hipStream_t s = (hipStream_t)stream;
+  KArgs A{};
+  fill_common(m, A, B);
+  if (memspace == BRBD_DEVICE) {
+    A.q = q; A.ldq = ldq; A.v = v; A.ldv = ldv; A.a = tau; A.lda = ldtau; A.out = ddq; A.ldout = ldddq;
+    return launch_algo(m, BRBD_ALGO_ABA, A, layout, s);
+  }
+  const size_t nq_ = mat_span(ldq, F.nq, B, layout), nv_ = mat_span(ldv, F.nv, B, layout),
+               nt_ = mat_span(ldtau, F.nv, B, layout), nd_ = mat_span(ldddq, F.nv, B, layout);
+  if ((rc = ensure_stage(m, padded(nq_) + padded(nv_) + padded(nt_) + padded(nd_)))) return rc;
+  Staged st{m, s};
+  double *dq = st.take(nq_), *dv = st.take(nv_), *dt = st.take(nt_), *dd = st.take(nd_);
+  HIP_TRY(hipMemcpyAsync(dq, q, nq_ * 8, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(dv, v, nv_ * 8, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(dt, tau, nt_ * 8, hipMemcpyHostToDevice, s));
+  if (ldddq != (layout == BRBD_BATCH_MAJOR ? B : F.nv))
+    HIP_TRY(hipMemcpyAsync(dd, ddq, nd_ * 8, hipMemcpyHostToDevice, s));
+  A.q = dq; A.ldq = ldq; A.v = dv; A.ldv = ldv; A.a = dt; A.lda = ldtau; A.out = dd; A.ldout = ldddq;
+  if ((rc = launch_algo(m, BRBD_ALGO_ABA, A, layout, s))) return rc;
+  HIP_TRY(hipMemcpyAsync(ddq, dd, nd_ * 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return BRBD_OK;
+}
+
+int brbd_fk_jacobians(brbd_model* m, int64_t B, const double* q, int64_t ldq, double* J, int64_t ldJ,
+                      double* oMi, int64_t ldoMi, int layout, int memspace, void* stream) {
+  int rc = check_common(m, B, layout, memspace);
+  if (rc) return rc;
+  const FlatModel& F = m->flat;
+  if ((rc = check_mat("q", q, ldq, F.nq, B, layout))) return rc;
+  if (!J && !oMi) return fail(BRBD_ERR_INVALID_ARGUMENT, "both outputs are NULL");
+  const int64_t jd = 6 * (int64_t)F.nv, md = 12 * (int64_t)F.njoints;
+  if (J && (rc = check_mat("J", J, ldJ, jd, B, layout))) return rc;
+  if (oMi && (rc = check_mat("oMi", oMi, ldoMi, md, B, layout))) return rc;
+  if (B == 0) return BRBD_OK;
+  DevGuard dg(m->device);
+  if (!dg.ok) return fail(BRBD_ERR_RUNTIME, "hipSetDevice failed");
+  hipStream_t s = (hipStream_t)stream;
+  KArgs A{};
+  fill_common(m, A, B);
+  if (memspace == BRBD_DEVICE) {
+    A.q = q; A.ldq = ldq; A.out = J; A.ldout = ldJ; A.out2 = oMi; A.ldout2 = ldoMi;
+    return launch_algo(m, BRBD_ALGO_FK_JAC, A, layout, s);
+  }
+  const size_t nq_ = mat_span(ldq, F.nq, B, layout);
+  const size_t nj_ = J ? mat_span(ldJ, jd, B, layout) : 0, nm_ = oMi ? mat_span(ldoMi, md, B, layout) : 0;
+  if ((rc = ensure_stage(m, padded(nq_) + padded(nj_) + padded(nm_)))) return rc;
+  Staged st{m, s};
+  double *dq = st.take(nq_), *dJ = J ? st.take(nj_) : nullptr, *dM = oMi ? st.take(nm_) : nullptr;
+  HIP_TRY(hipMemcpyAsync(dq, q, nq_ * 8, hipMemcpyHostToDevice, s));
+  if (J && ldJ != (layout == BRBD_BATCH_MAJOR ? B : jd)) HIP_TRY(hipMemcpyAsync(dJ, J, nj_ * 8, hipMemcpyHostToDevice, s));
+  if (oMi && ldoMi != (layout == BRBD_BATCH_MAJOR ? B : md))
+    HIP_TRY(hipMemcpyAsync(dM, oMi, nm_ * 8, hipMemcpyHostToDevice, s));
+  A.q = dq; A.ldq = ldq; A.out = dJ; A.ldout = ldJ; A.out2 = dM; A.ldout2 = ldoMi;
+  if ((rc = launch_algo(m, BRBD_ALGO_FK_JAC, A, layout, s))) return rc;
+  if (J) HIP_TRY(hipMemcpyAsync(J, dJ, nj_ * 8, hipMemcpyDeviceToHost, s));
+  if (oMi) HIP_TRY(hipMemcpyAsync(oMi, dM, nm_ * 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return BRBD_OK;
+}
+
+int brbd_rnea_derivatives(brbd_model* m, int64_t B, const double* q, int64_t ldq, const double* v,
+                          int64_t ldv, const double* a, int64_t lda, double* dtau_dq, int64_t lddq,
+                          double* dtau_dv, int64_t lddv, double* dtau_da, int64_t ldda, double* tau,
+                          int64_t ldtau, int layout, int memspace, void* stream) {
+  int rc = check_common(m, B, layout, memspace);
+  if (rc) return rc;
+  const FlatModel& F = m->flat;
+  const int64_t nn = (int64_t)F.nv * F.nv;
+  if ((rc = check_mat("q", q, ldq, F.nq, B, layout))) return rc;
+  if ((rc = check_mat("v", v, ldv, F.nv, B, layout))) return rc;
+  if ((rc = check_mat("a", a, lda, F.nv, B, layout))) return rc;
+  if ((rc = check_mat("dtau_dq", dtau_dq, lddq, nn, B, layout))) return rc;
+  if ((rc = check_mat("dtau_dv", dtau_dv, lddv, nn, B, layout))) return rc;
+  if (dtau_da && (rc = check_mat("dtau_da", dtau_da, ldda, nn, B, layout))) return rc;
+  if (tau && (rc = check_mat("tau", tau, ldtau, F.nv, B, layout))) return rc;
+  if (!F.depth_first)
+    return fail(BRBD_ERR_UNSUPPORTED,
+                "computeRNEADerivatives needs depth-first joint numbering (contiguous subtrees), as "
+                "pinocchio's Data::computeNvSubtree assumes");
+  if (B == 0) return BRBD_OK;
+  DevGuard dg(m->device);
+  if (!dg.ok) return fail(BRBD_ERR_RUNTIME, "hipSetDevice failed");
+  hipStream_t s = (hipStream_t)stream;
+  DerivArgs D{};
+  D.tab = m->d_tab;
+  D.nvsub = m->d_nvsub;
+  D.njoints = F.njoints; D.nq = F.nq; D.nv = F.nv;
+  D.B = B;
+  D.ntiles = (B + WAVE - 1) / WAVE;
+  D.gx = F.gravity[0]; D.gy = F.gravity[1]; D.gz = F.gravity[2];
+  auto run = [&](const double* dq_, const double* dv_, const double* da_, double* pdq, double* pdv,
+                 double* pda, double* pt) -> int {
+    D.q = dq_; D.ldq = ldq; D.v = dv_; D.ldv = ldv; D.a = da_; D.lda = lda;
+    D.dq = pdq; D.lddq = lddq; D.dv = pdv; D.lddv = lddv; D.da = pda; D.ldda = ldda; D.tau = pt; D.ldtau = ldtau;
+    if (m->max_waves[BRBD_ALGO_RNEA_DERIV] == 0)
+      m->max_waves[BRBD_ALGO_RNEA_DERIV] = resident_waves(m, rnea_deriv_kernel<1>, WAVE);
+    const int64_t grid = D.ntiles < m->max_waves[3] ? D.ntiles : m->max_waves[3];
+    D.ws_stride = (int64_t)deriv_ws_per_lane(F) * WAVE;
+    int r = ensure_ws(m, (size_t)grid * D.ws_stride);
+    if (r) return r;
+    D.ws = m->d_ws;
+    Timer tm{m, BRBD_ALGO_RNEA_DERIV, s};
+    if ((r = tm.begin())) return r;
+    const dim3 g((unsigned)grid), b(WAVE);
+    if (layout == BRBD_BATCH_MAJOR) hipLaunchKernelGGL(rnea_deriv_kernel<1>, g, b, 0, s, D);
+    else hipLaunchKernelGGL(rnea_deriv_kernel<0>, g, b, 0, s, D);
+    HIP_TRY(hipGetLastError());
+    return tm.end();
+  };
+  if (memspace == BRBD_DEVICE) return run(q, v, a, dtau_dq, dtau_dv, dtau_da, tau);
+  const size_t nq_ = mat_span(ldq, F.nq, B, layout), nv_ = mat_span(ldv, F.nv, B, layout),
+               na_ = mat_span(lda, F.nv, B, layout);
+  const size_t n1 = mat_span(lddq, nn, B, layout), n2 = mat_span(lddv, nn, B, layout),
+               n3 = dtau_da ? mat_span(ldda, nn, B, layout) : 0, n4 = tau ? mat_span(ldtau, F.nv, B, layout) : 0;
+  if ((rc = ensure_stage(m, padded(nq_) + padded(nv_) + padded(na_) + padded(n1) + padded(n2) + padded(n3) + padded(n4))))
+    return rc;
+  Staged st{m, s};
+  double *dq_ = st.take(nq_), *dv_ = st.take(nv_), *da_ = st.take(na_);
+  double *p1 = st.take(n1), *p2 = st.take(n2), *p3 = dtau_da ? st.take(n3) : nullptr, *p4 = tau ? st.take(n4) : nullptr;
+  HIP_TRY(hipMemcpyAsync(dq_, q, nq_ * 8, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(dv_, v, nv_ * 8, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(da_, a, na_ * 8, hipMemcpyHostToDevice, s));
+  // outputs with caller padding: preserve it
+  const int64_t tight_nn = layout == BRBD_BATCH_MAJOR ? B : nn, tight_nv = layout == BRBD_BATCH_MAJOR ? B : F.nv;
+  if (lddq != tight_nn) HIP_TRY(hipMemcpyAsync(p1, dtau_dq, n1 * 8, hipMemcpyHostToDevice, s));
+  if (lddv != tight_nn) HIP_TRY(hipMemcpyAsync(p2, dtau_dv, n2 * 8, hipMemcpyHostToDevice, s));
+  if (p3 && ldda != tight_nn) HIP_TRY(hipMemcpyAsync(p3, dtau_da, n3 * 8, hipMemcpyHostToDevice, s));
+  if (p4 && ldtau != tight_nv) HIP_TRY(hipMemcpyAsync(p4, tau, n4 * 8, hipMemcpyHostToDevice, s));
+  if ((rc = run(dq_, dv_, da_, p1, p2, p3, p4))) return rc;
+  HIP_TRY(hipMemcpyAsync(dtau_dq, p1, n1 * 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(dtau_dv, p2, n2 * 8, hipMemcpyDeviceToHost, s));
+  if (p3) HIP_TRY(hipMemcpyAsync(dtau_da, p3, n3 * 8, hipMemcpyDeviceToHost, s));
+  if (p4) HIP_TRY(hipMemcpyAsync(tau, p4, n4 * 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return BRBD_OK;
+}
+
+static int transpose_common(int device, int64_t dof, int64_t B, const double* src, int64_t ld_src,
+                            double* dst, int64_t ld_dst, void* stream, int to_bm) {
+  if (!src || !dst) return fail(BRBD_ERR_INVALID_ARGUMENT, "NULL pointer");
+  if (dof < 0 || B < 0) return fail(BRBD_ERR_INVALID_ARGUMENT, "negative size");
+  if (dof == 0 || B == 0) return BRBD_OK;
+  const int64_t need_src = to_bm ? dof : B, need_dst = to_bm ? B : dof;
+  if (ld_src < need_src || ld_dst < need_dst) return fail(BRBD_ERR_INVALID_ARGUMENT, "leading dimension too small");
+  DevGuard dg(device);
+  if (!dg.ok) return fail(BRBD_ERR_RUNTIME, "hipSetDevice failed");
+  const dim3 g((unsigned)((B + 31) / 32), (unsigned)((dof + 31) / 32)), b(256);
+  hipLaunchKernelGGL(transpose_kernel, g, b, 0, (hipStream_t)stream, src, ld_src, dst, ld_dst, dof, B, to_bm);
+  HIP_TRY(hipGetLastError());
+  return BRBD_OK;
+}
+
+int brbd_transpose_to_batch_major(int device, int64_t dof, int64_t B, const double* src, int64_t ld_src,
+                                  double* dst, int64_t ld_dst, void* stream) {
+  return transpose_common(device, dof, B, src, ld_src, dst, ld_dst, stream, 1);
+}
+int brbd_transpose_to_instance_major(int device, int64_t dof, int64_t B, const double* src,
+                                     int64_t ld_src, double* dst, int64_t ld_dst, void* stream) {
+  return transpose_common(device, dof, B, src, ld_src, dst, ld_dst, stream, 0);
+}
+
+int brbd_set_timing(brbd_model* m, int enabled) {
+  if (!m) return fail(BRBD_ERR_INVALID_ARGUMENT, "model handle is NULL");
+  m->timing = enabled != 0;
+  return BRBD_OK;
+}
+
+int brbd_kernel_time(brbd_model* m, int algo, int32_t* launches, double* total_ms) {
+  if (!m || algo < 0 || algo > 3) return fail(BRBD_ERR_INVALID_ARGUMENT, "bad model handle or algo");
+  DevGuard dg(m->device);
+  std::vector<TimedLaunch> v;
+  {
+    std::lock_guard<std::mutex> g(m->mu);
+    v.swap(m->timed[algo]);
+  }
+  double sum = 0.0;
+  for (auto& t : v) {
+    HIP_TRY(hipEventSynchronize(t.stop));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, t.start, t.stop));
+    sum += ms;
+    (void)hipEventDestroy(t.start);
+    (void)hipEventDestroy(t.stop);
+  }
+  if (launches) *launches = (int32_t)v.size();
+  if (total_ms) *total_ms = sum;
+  return BRBD_OK;
+}
+
+}  // extern "C"

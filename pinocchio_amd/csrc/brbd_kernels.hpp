@@ -1,0 +1,864 @@
+// brbd_kernels.hpp -- generic (table-driven) batch kernels: RNEA, ABA (WORLD), FK + Jacobians.
+//
+// Execution model
+//   * one lane = one instance, one wave (64 lanes) = one workgroup, grid-stride over tiles of 64
+//     instances, so the per-wave spill workspace is bounded by the grid, not by the batch;
+//   * the kinematic tree is walked by a depth-first PROGRAM built by the flattener
+//     (brbd_flatten.hpp): a joint's forward visit, its subtree, then its backward visit.  Only the
+//     joints on the current root path are live, chains hand state parent->child and
+//     child->parent in registers, and only branching joints spill to the workspace;
+//   * every control decision (op kind, joint kind, flags) is wave-uniform: no divergence.
+//
+// Reference recursions: algorithm/rnea.hxx:45-161, algorithm/aba.hxx:102-294,
+// algorithm/kinematics.hxx:52-97, algorithm/jacobian.hxx:38-95.
+#pragma once
+#include "brbd_device.hpp"
+
+namespace brbd {
+
+constexpr int WAVE = 64;
+
+struct KArgs {
+  const JointConst* tab;
+  const Op* prog;   // pass 1+2 program (FWD/BWD ops)
+  const Op* prog3;  // ABA pass 3 program (FWD ops only)
+  int32_t nops, nops3;
+  int32_t njoints, nq, nv;
+  int32_t maxdepth, maxbranch;
+  int64_t B;
+  int64_t ntiles;
+  double* ws;         // spill workspace
+  int64_t ws_stride;  // doubles per wave
+  double gx, gy, gz;  // gravity
+  const double* q; int64_t ldq;
+  const double* v; int64_t ldv;
+  const double* a; int64_t lda;  // RNEA: a, ABA: tau
+  double* out; int64_t ldout;    // RNEA: tau, ABA: ddq, FKJ: J
+  double* out2; int64_t ldout2;  // FKJ: oMi
+};
+
+// Element (d, b) of a dof x B matrix in the two boundary layouts (include/brbd.h).
+template <int LAYOUT>
+struct Mat {
+  double* p;
+  int64_t ld;
+  int64_t b;
+  DI double get(int d) const { return LAYOUT ? p[(int64_t)d * ld + b] : p[b * ld + d]; }
+  DI void put(int d, double x) const {
+    if (LAYOUT) p[(int64_t)d * ld + b] = x; else p[b * ld + d] = x;
+  }
+};
+
+// Wave-private workspace slot s of this lane: coalesced 512-byte rows.
+DI double wsld(const double* w, int slot) { return w[(int64_t)slot * WAVE]; }
+DI void wsst(double* w, int slot, double x) { w[(int64_t)slot * WAVE] = x; }
+
+// ---- joint kinematics: liMi = placement * M(q) -------------------------------------------------
+// have_sc: (s, c) already known (backward visit / pass 3), skip sincos.
+template <int LAYOUT>
+DI void joint_liMi(const JointConst& jc, const Mat<LAYOUT>& q, bool have_sc, double& s, double& c,
+                   double* R, double* t) {
+  const int jt = jc.jtype, iq = jc.idx_q;
+  switch (jt) {
+    case JT_RX: case JT_RY: case JT_RZ: case JT_RUBX: case JT_RUBY: case JT_RUBZ: {
+      if (!have_sc) {
+        if (jt <= JT_RZ) {
+          sincos(q.get(iq), &s, &c);  // math/sincos.hpp:47-61
+        } else {
+          c = q.get(iq);  // joint-revolute-unbounded.hpp:153-162
+          s = q.get(iq + 1);
+        }
+      }
+      const int k = jt <= JT_RZ ? jt - JT_RX : jt - JT_RUBX;
+      if (k == 0) revolute_liMi<0>(jc.R, s, c, R);
+      else if (k == 1) revolute_liMi<1>(jc.R, s, c, R);
+      else revolute_liMi<2>(jc.R, s, c, R);
+      t[0] = jc.t[0]; t[1] = jc.t[1]; t[2] = jc.t[2];
+      break;
+    }
+    case JT_PX: case JT_PY: case JT_PZ: {
+      // joint-prismatic.hpp:262-272
+      const int k = jt - JT_PX;
+      const double x = q.get(iq);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) R[i] = jc.R[i];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const double col = k == 0 ? jc.R[3 * r] : (k == 1 ? jc.R[3 * r + 1] : jc.R[3 * r + 2]);
+        t[r] = jc.t[r] + x * col;
+      }
+      break;
+    }
+    case JT_FF: {
+      // joint-free-flyer.hpp:332-374
+      double Rq[9], p[3], Rp[3];
+      quat_to_R(q.get(iq + 3), q.get(iq + 4), q.get(iq + 5), q.get(iq + 6), Rq);
+      p[0] = q.get(iq); p[1] = q.get(iq + 1); p[2] = q.get(iq + 2);
+      rot_mul(jc.R, Rq, R);
+      rot_vec(jc.R, p, Rp);
+      t[0] = jc.t[0] + Rp[0]; t[1] = jc.t[1] + Rp[1]; t[2] = jc.t[2] + Rp[2];
+      break;
+    }
+    default: {  // JT_SPH, joint-spherical.hpp:525-589
+      double Rq[9];
+      quat_to_R(q.get(iq), q.get(iq + 1), q.get(iq + 2), q.get(iq + 3), Rq);
+      rot_mul(jc.R, Rq, R);
+      t[0] = jc.t[0]; t[1] = jc.t[1]; t[2] = jc.t[2];
+      break;
+    }
+  }
+}
+
+// Dense S * x for the joint (x = joint velocity or acceleration read from `m`)
+template <int LAYOUT>
+DI void joint_S_times(const JointConst& jc, const Mat<LAYOUT>& m, double* o) {
+  const int iv = jc.idx_v;
+  if (jc.nvj == 1) {
+    const double x = m.get(iv);
+    const int comp = jc.comp;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) o[k] = (k == comp) ? x : 0.0;
+  } else if (jc.nvj == 6) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) o[k] = m.get(iv + k);
+  } else {
+    o[0] = o[1] = o[2] = 0.0;
+    o[3] = m.get(iv); o[4] = m.get(iv + 1); o[5] = m.get(iv + 2);
+  }
+}
+
+// =================================================================================== RNEA
+// workspace slots per lane: F[depth][8] = f(6) + (s, c);  VA[bslot][12] = v(6) + a_gf(6)
+template <int LAYOUT>
+__global__ __launch_bounds__(WAVE) void rnea_kernel(const KArgs A) {
+  const int lane = threadIdx.x;
+  double* const wsl = A.ws + (int64_t)blockIdx.x * A.ws_stride + lane;
+  const int VA0 = A.maxdepth * 8;
+  for (int64_t tile = blockIdx.x; tile < A.ntiles; tile += gridDim.x) {
+    const int64_t b0 = tile * WAVE + lane;
+    const bool valid = b0 < A.B;
+    const int64_t b = valid ? b0 : A.B - 1;
+    const Mat<LAYOUT> q{const_cast<double*>(A.q), A.ldq, b};
+    const Mat<LAYOUT> vin{const_cast<double*>(A.v), A.ldv, b};
+    const Mat<LAYOUT> ain{const_cast<double*>(A.a), A.lda, b};
+    const Mat<LAYOUT> tau{A.out, A.ldout, b};
+    double v[6], a[6], carry[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) v[k] = a[k] = carry[k] = 0.0;
+
+    for (int s = 0; s < A.nops; ++s) {
+      const Op op = load_op(A.prog, s);
+      JointConst jc;
+      load_joint(A.tab, op.joint, jc);
+      const int fl = op.flags;
+      double R[9], t[3], f[6], sn = 0.0, cs = 1.0;
+      if (!(fl & OP_BWD)) {
+        // ---------------- forward visit (rnea.hxx:45-79) ----------------
+        double vp[6], ap[6];
+        if (fl & F_PARENT_ROOT) {  // rnea.hxx:137-138: v[0] = 0, a_gf[0] = -gravity
+#pragma unroll
+          for (int k = 0; k < 6; ++k) vp[k] = ap[k] = 0.0;
+          ap[0] = -A.gx; ap[1] = -A.gy; ap[2] = -A.gz;
+        } else if (fl & F_FROM_REGS) {
+#pragma unroll
+          for (int k = 0; k < 6; ++k) { vp[k] = v[k]; ap[k] = a[k]; }
+        } else {
+          const int base = VA0 + op.bslot * 12;
+#pragma unroll
+          for (int k = 0; k < 6; ++k) { vp[k] = wsld(wsl, base + k); ap[k] = wsld(wsl, base + 6 + k); }
+        }
+        joint_liMi<LAYOUT>(jc, q, false, sn, cs, R, t);
+        double vJ[6], Sa[6], tmp[6];
+        joint_S_times<LAYOUT>(jc, vin, vJ);
+        joint_S_times<LAYOUT>(jc, ain, Sa);
+        if (fl & F_PARENT_ROOT) {  // :63-65, velocity propagation guarded by parent > 0
+#pragma unroll
+          for (int k = 0; k < 6; ++k) v[k] = vJ[k];
+        } else {
+          se3_actinv_motion(R, t, vp, tmp);
+#pragma unroll
+          for (int k = 0; k < 6; ++k) v[k] = vJ[k] + tmp[k];
+        }
+        motion_cross(v, vJ, a);             // :67 (c = 0)
+        se3_actinv_motion(R, t, ap, tmp);   // :69 (not guarded)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) a[k] = (a[k] + Sa[k]) + tmp[k];
+        double h[6];
+        inertia_mul(jc.m, jc.c, jc.I, v, h);  // :73
+        inertia_mul(jc.m, jc.c, jc.I, a, f);  // :74
+        force_cross(v, h, tmp);               // :75
+#pragma unroll
+        for (int k = 0; k < 6; ++k) f[k] += tmp[k];
+        if (fl & F_PUSH_BRANCH) {
+          const int base = VA0 + op_own_bslot(fl) * 12;
+#pragma unroll
+          for (int k = 0; k < 6; ++k) { wsst(wsl, base + k, v[k]); wsst(wsl, base + 6 + k, a[k]); }
+        }
+        if (!(fl & F_LEAF)) {
+          const int base = op.depth * 8;
+#pragma unroll
+          for (int k = 0; k < 6; ++k) wsst(wsl, base + k, f[k]);
+          wsst(wsl, base + 6, sn);
+          wsst(wsl, base + 7, cs);
+          continue;
+        }
+      } else {
+        // ---------------- backward visit of a non-leaf joint (rnea.hxx:92-107) ----------------
+        const int base = op.depth * 8;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) f[k] = wsld(wsl, base + k);
+        sn = wsld(wsl, base + 6);
+        cs = wsld(wsl, base + 7);
+        if (fl & F_CARRY_IN) {
+#pragma unroll
+          for (int k = 0; k < 6; ++k) f[k] += carry[k];
+        }
+        joint_liMi<LAYOUT>(jc, q, true, sn, cs, R, t);
+      }
+      // ---- common tail: tau = S^T f (+ armature * a), hand f to the parent ----
+      {
+        const int iv = jc.idx_v;
+        if (jc.nvj == 1) {
+          const int comp = jc.comp;
+          double x = f[0];
+#pragma unroll
+          for (int k = 1; k < 6; ++k) x = (k == comp) ? f[k] : x;
+          x += jc.arm[0] * ain.get(iv);  // rnea.hxx:158
+          if (valid) tau.put(iv, x);
+        } else if (jc.nvj == 6) {
+#pragma unroll
+          for (int k = 0; k < 6; ++k) {
+            const double x = f[k] + jc.arm[k] * ain.get(iv + k);
+            if (valid) tau.put(iv + k, x);
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const double x = f[3 + k] + jc.arm[k] * ain.get(iv + k);
+            if (valid) tau.put(iv + k, x);
+          }
+        }
+        if (!(fl & F_PARENT_ROOT)) {  // :105-106
+          double up[6];
+          se3_act_force(R, t, f, up);
+          if (fl & F_CARRY_REGS) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) carry[k] = up[k];
+          } else {
+            const int pbase = (op.depth - 1) * 8;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) wsst(wsl, pbase + k, wsld(wsl, pbase + k) + up[k]);
+          }
+        }
+      }
+    }
+  }
+}
+
+// =================================================================================== ABA (WORLD)
+// J columns of a joint in the world frame: oMi.act(S) (aba.hxx:124, jacobian.hxx:59)
+// 1-dof aligned: revolute k -> [t x R[:,k]; R[:,k]], prismatic k -> [R[:,k]; 0]
+DI void jcol_1dof(const JointConst& jc, const double* R, const double* t, double* J) {
+  const int comp = jc.comp;
+  const int k = comp >= 3 ? comp - 3 : comp;
+  double col[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) col[r] = k == 0 ? R[3 * r] : (k == 1 ? R[3 * r + 1] : R[3 * r + 2]);
+  if (comp >= 3) {
+    cross3(t, col, J);
+    J[3] = col[0]; J[4] = col[1]; J[5] = col[2];
+  } else {
+    J[0] = col[0]; J[1] = col[1]; J[2] = col[2];
+    J[3] = J[4] = J[5] = 0.0;
+  }
+}
+// multi-dof: FF (6 columns: action matrix, se3-tpl.hpp:178-191) or spherical (3 angular columns)
+template <int NV>
+DI void jcols_multi(const double* R, const double* t, double* J /* NV x 6 */) {
+  constexpr int first_ang = NV == 6 ? 3 : 0;
+#pragma unroll
+  for (int c = 0; c < NV; ++c) {
+    double col[3];
+    const int j = c >= first_ang ? c - first_ang : c;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) col[r] = R[3 * r + j];
+    if (c >= first_ang) {
+      cross3(t, col, J + 6 * c);
+      J[6 * c + 3] = col[0]; J[6 * c + 4] = col[1]; J[6 * c + 5] = col[2];
+    } else {
+      J[6 * c + 0] = col[0]; J[6 * c + 1] = col[1]; J[6 * c + 2] = col[2];
+      J[6 * c + 3] = J[6 * c + 4] = J[6 * c + 5] = 0.0;
+    }
+  }
+}
+
+// world kinematics of one joint from its parent's (oMp, ovp): oMi, ov, bias = ovp x ov
+// (aba.hxx:115-132).  root: parent == 0.
+template <int LAYOUT>
+DI void aba_kin(const JointConst& jc, const Mat<LAYOUT>& q, const Mat<LAYOUT>& vin, bool root,
+                bool have_sc, double& sn, double& cs, const double* Rp, const double* tp,
+                const double* ovp, double* R, double* t, double* ov, double* bias) {
+  double Rl[9], tl[3];
+  joint_liMi<LAYOUT>(jc, q, have_sc, sn, cs, Rl, tl);
+  if (root) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = Rl[i];
+    t[0] = tl[0]; t[1] = tl[1]; t[2] = tl[2];
+  } else {  // se3-tpl.hpp:311-315
+    double Rt[3];
+    rot_mul(Rp, Rl, R);
+    rot_vec(Rp, tl, Rt);
+    t[0] = tp[0] + Rt[0]; t[1] = tp[1] + Rt[1]; t[2] = tp[2] + Rt[2];
+  }
+  double vJ[6], ovJ[6];
+  joint_S_times<LAYOUT>(jc, vin, vJ);
+  se3_act_motion(R, t, vJ, ovJ);  // aba.hxx:126
+  if (root) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { ov[k] = ovJ[k]; bias[k] = 0.0; }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) ov[k] = ovJ[k] + ovp[k];  // :127-128
+    motion_cross(ovp, ov, bias);                           // :131-132
+  }
+}
+
+// own world inertia (packed sym6) and bias force of = ov x* (Y ov)  (aba.hxx:134-138)
+DI void aba_own_inertia(const JointConst& jc, const double* R, const double* t, const double* ov,
+                        double* Ia, double* of) {
+  double cw[3], Iw[6], h[6];
+  inertia_to_world(R, t, jc.m, jc.c, jc.I, cw, Iw);
+  inertia_to_sym6(jc.m, cw, Iw, Ia);
+  inertia_mul(jc.m, cw, Iw, ov, h);
+  force_cross(ov, h, of);
+}
+
+// workspace slots per lane (ABA):
+//   KIN[depth][18]   = oMi (R 9, t 3) + ov (6)        (non-leaf joints, forward -> backward visit)
+//   ACC[bslot][27]   = Ia (21) + of (6)               (branching joints: own + children)
+//   KB[bslot][18]    = oMi + ov of a branching joint  (for its 2nd.. children, pass 1)
+//   HAND[...]        = per joint pass 2 -> pass 3 record (hand_off from the flattener)
+//   K3[bslot][24]    = oMi + ov + a of a branching joint (pass 3)
+struct AbaLayout {
+  int kin0, acc0, kb0, hand0, k30;
+};
+DI AbaLayout aba_layout(const KArgs& A, int nhand) {
+  AbaLayout L;
+  L.kin0 = 0;
+  L.acc0 = L.kin0 + A.maxdepth * 18;
+  L.kb0 = L.acc0 + A.maxbranch * 27;
+  L.k30 = L.kb0 + A.maxbranch * 18;
+  L.hand0 = L.k30 + A.maxbranch * 24;
+  (void)nhand;
+  return L;
+}
+
+// Backward visit arithmetic for an NV-dof joint (aba.hxx:153-193).  Ia/of hold the accumulated
+// articulated inertia / bias force of the joint on entry and the contribution for the parent on
+// exit.  Writes the pass-3 hand-off record, or ddq directly for joints attached to the universe.
+template <int NV, int LAYOUT>
+DI void aba_backward(const KArgs& A, const JointConst& jc, double* wsl, int hand0, bool root,
+                     bool valid, const double* J, const double* bias, const Mat<LAYOUT>& tauin,
+                     const Mat<LAYOUT>& ddq, double* Ia, double* of) {
+  const int iv = jc.idx_v;
+  double u[NV], U[NV * 6], D[NV * NV], Dinv[NV * NV], UD[NV * 6];
+#pragma unroll
+  for (int c = 0; c < NV; ++c) u[c] = tauin.get(iv + c) - dot6(J + 6 * c, of);  // :173 (u = tau)
+#pragma unroll
+  for (int c = 0; c < NV; ++c) sym6_mulvec(Ia, J + 6 * c, U + 6 * c);  // :175
+#pragma unroll
+  for (int r = 0; r < NV; ++r)
+#pragma unroll
+    for (int c = r; c < NV; ++c) {
+      double d = dot6(J + 6 * r, U + 6 * c);  // :176
+      if (r == c) d += jc.arm[r];             // :179
+      D[NV * r + c] = d;
+      D[NV * c + r] = d;
+    }
+  if (NV == 1) Dinv[0] = 1.0 / D[0];
+  else spd_inverse<NV>(D, Dinv);  // :181
+#pragma unroll
+  for (int c = 0; c < NV; ++c)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      double s = 0.0;
+#pragma unroll
+      for (int r = 0; r < NV; ++r) s += U[6 * r + k] * Dinv[NV * r + c];
+      UD[6 * c + k] = s;  // :182
+    }
+  if (root) {
+    // parent is the universe: a = a_gf[0] + bias(=0) = -gravity is known now, so pass 3 of this
+    // joint collapses to ddq = Dinv u - UDinv^T a (aba.hxx:223-226)
+    double a0[6] = {-A.gx, -A.gy, -A.gz, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int r = 0; r < NV; ++r) {
+      double s = 0.0;
+#pragma unroll
+      for (int c = 0; c < NV; ++c) s += Dinv[NV * r + c] * u[c];
+      s -= dot6(UD + 6 * r, a0);
+      if (valid) ddq.put(iv + r, s);
+    }
+    return;
+  }
+  // hand-off record for pass 3: UDinv (6 NV), then NV==1: Dinv*u ; NV>1: Dinv (NV*NV), u (NV)
+  const int h = hand0 + jc.hand_off;
+#pragma unroll
+  for (int k = 0; k < 6 * NV; ++k) wsst(wsl, h + k, UD[k]);
+  if (NV == 1) {
+    wsst(wsl, h + 6, Dinv[0] * u[0]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < NV * NV; ++k) wsst(wsl, h + 6 * NV + k, Dinv[k]);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) wsst(wsl, h + 6 * NV + NV * NV + k, u[k]);
+  }
+  // :186 Ia -= UDinv U^T
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = i; j < 6; ++j) {
+      double s = 0.0;
+#pragma unroll
+      for (int c = 0; c < NV; ++c) s += UD[6 * c + i] * U[6 * c + j];
+      Ia[sidx(i, j)] -= s;
+    }
+  // :188-189 of += Ia * a_gf + UDinv * u
+  double t1[6];
+  sym6_mulvec(Ia, bias, t1);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    double s = t1[k];
+#pragma unroll
+    for (int c = 0; c < NV; ++c) s += UD[6 * c + k] * u[c];
+    of[k] += s;
+  }
+}
+
+// hand-off record sizes (doubles) by joint dof count; +2 for the cached (s, c) at the end
+__host__ __device__ constexpr int hand_size(int nvj) {
+  return (nvj == 1 ? 7 : 6 * nvj + nvj * nvj + nvj) + 2;
+}
+
+template <int LAYOUT>
+__global__ __launch_bounds__(WAVE) void aba_kernel(const KArgs A) {
+  const int lane = threadIdx.x;
+  double* const wsl = A.ws + (int64_t)blockIdx.x * A.ws_stride + lane;
+  const AbaLayout L = aba_layout(A, 0);
+  for (int64_t tile = blockIdx.x; tile < A.ntiles; tile += gridDim.x) {
+    const int64_t b0 = tile * WAVE + lane;
+    const bool valid = b0 < A.B;
+    const int64_t b = valid ? b0 : A.B - 1;
+    const Mat<LAYOUT> q{const_cast<double*>(A.q), A.ldq, b};
+    const Mat<LAYOUT> vin{const_cast<double*>(A.v), A.ldv, b};
+    const Mat<LAYOUT> tauin{const_cast<double*>(A.a), A.lda, b};
+    const Mat<LAYOUT> ddq{A.out, A.ldout, b};
+
+    // ------------------------------------------------ passes 1 + 2, depth-first
+    {
+      double R[9], t[3], ov[6];       // state of the most recent forward visit
+      double cIa[21], cof[6];         // carry registers child -> parent
+#pragma unroll
+      for (int k = 0; k < 9; ++k) R[k] = 0.0;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) t[k] = 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) ov[k] = cof[k] = 0.0;
+#pragma unroll
+      for (int k = 0; k < 21; ++k) cIa[k] = 0.0;
+
+      for (int s = 0; s < A.nops; ++s) {
+        const Op op = load_op(A.prog, s);
+        JointConst jc;
+      load_joint(A.tab, op.joint, jc);
+        const int fl = op.flags;
+        const bool root = fl & F_PARENT_ROOT;
+        double Ia[21], of[6], bias[6];
+        double sn = 0.0, cs = 1.0;
+        if (!(fl & OP_BWD)) {
+          // ---------------- forward visit (aba.hxx:102-139) ----------------
+          double Rp[9], tp[3], ovp[6];
+          if (fl & F_FROM_REGS) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) Rp[k] = R[k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) tp[k] = t[k];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) ovp[k] = ov[k];
+          } else if (!root) {
+            const int base = L.kb0 + op.bslot * 18;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) Rp[k] = wsld(wsl, base + k);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) tp[k] = wsld(wsl, base + 9 + k);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) ovp[k] = wsld(wsl, base + 12 + k);
+          } else {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) Rp[k] = 0.0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) tp[k] = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) ovp[k] = 0.0;
+          }
+          aba_kin<LAYOUT>(jc, q, vin, root, false, sn, cs, Rp, tp, ovp, R, t, ov, bias);
+          // (s, c) of revolute joints go to the hand-off record for pass 3
+          {
+            const int h = L.hand0 + jc.hand_off + hand_size(jc.nvj) - 2;
+            wsst(wsl, h, sn);
+            wsst(wsl, h + 1, cs);
+          }
+          if (fl & F_PUSH_BRANCH) {
+            const int bs = op_own_bslot(fl);
+            const int kb = L.kb0 + bs * 18;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) wsst(wsl, kb + k, R[k]);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) wsst(wsl, kb + 9 + k, t[k]);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) wsst(wsl, kb + 12 + k, ov[k]);
+            // accumulator starts with the joint's own inertia and bias force (aba.hxx:134-138)
+            aba_own_inertia(jc, R, t, ov, Ia, of);
+            const int ac = L.acc0 + bs * 27;
+#pragma unroll
+            for (int k = 0; k < 21; ++k) wsst(wsl, ac + k, Ia[k]);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) wsst(wsl, ac + 21 + k, of[k]);
+          }
+          if (!(fl & F_LEAF)) {
+            const int base = L.kin0 + op.depth * 18;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) wsst(wsl, base + k, R[k]);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) wsst(wsl, base + 9 + k, t[k]);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) wsst(wsl, base + 12 + k, ov[k]);
+            continue;
+          }
+          aba_own_inertia(jc, R, t, ov, Ia, of);
+          // leaf: fall through to the backward arithmetic with (R, t, ov, bias) in registers
+          double J[36];
+          if (jc.nvj == 1) {
+            jcol_1dof(jc, R, t, J);
+            aba_backward<1, LAYOUT>(A, jc, wsl, L.hand0, root, valid, J, bias, tauin, ddq, Ia, of);
+          } else if (jc.nvj == 6) {
+            jcols_multi<6>(R, t, J);
+            aba_backward<6, LAYOUT>(A, jc, wsl, L.hand0, root, valid, J, bias, tauin, ddq, Ia, of);
+          } else {
+            jcols_multi<3>(R, t, J);
+            aba_backward<3, LAYOUT>(A, jc, wsl, L.hand0, root, valid, J, bias, tauin, ddq, Ia, of);
+          }
+        } else {
+          // ---------------- backward visit of a non-leaf joint (aba.hxx:153-193) ----------------
+          double Rb[9], tb[3], ovb[6];
+          const int base = L.kin0 + op.depth * 18;
+#pragma unroll
+          for (int k = 0; k < 9; ++k) Rb[k] = wsld(wsl, base + k);
+#pragma unroll
+          for (int k = 0; k < 3; ++k) tb[k] = wsld(wsl, base + 9 + k);
+#pragma unroll
+          for (int k = 0; k < 6; ++k) ovb[k] = wsld(wsl, base + 12 + k);
+          double J[36], vJ[6], ovJ[6];
+          // bias = ov_parent x ov with ov_parent = ov - oMi.act(vJ) (aba.hxx:126-132)
+          joint_S_times<LAYOUT>(jc, vin, vJ);
+          se3_act_motion(Rb, tb, vJ, ovJ);
+          if (root) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) bias[k] = 0.0;
+          } else {
+            double ovp[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) ovp[k] = ovb[k] - ovJ[k];
+            motion_cross(ovp, ovb, bias);
+          }
+          if (fl & F_MULTI) {
+            const int ac = L.acc0 + op_own_bslot(fl) * 27;
+#pragma unroll
+            for (int k = 0; k < 21; ++k) Ia[k] = wsld(wsl, ac + k);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) of[k] = wsld(wsl, ac + 21 + k);
+          } else {
+            aba_own_inertia(jc, Rb, tb, ovb, Ia, of);
+#pragma unroll
+            for (int k = 0; k < 21; ++k) Ia[k] += cIa[k];  // aba.hxx:190-191 (single child)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) of[k] += cof[k];
+          }
+          if (jc.nvj == 1) {
+            jcol_1dof(jc, Rb, tb, J);
+            aba_backward<1, LAYOUT>(A, jc, wsl, L.hand0, root, valid, J, bias, tauin, ddq, Ia, of);
+          } else if (jc.nvj == 6) {
+            jcols_multi<6>(Rb, tb, J);
+            aba_backward<6, LAYOUT>(A, jc, wsl, L.hand0, root, valid, J, bias, tauin, ddq, Ia, of);
+          } else {
+            jcols_multi<3>(Rb, tb, J);
+            aba_backward<3, LAYOUT>(A, jc, wsl, L.hand0, root, valid, J, bias, tauin, ddq, Ia, of);
+          }
+        }
+        // ---- hand the articulated contribution to the parent (aba.hxx:190-191) ----
+        if (!root) {
+          if (fl & F_CARRY_REGS) {
+#pragma unroll
+            for (int k = 0; k < 21; ++k) cIa[k] = Ia[k];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) cof[k] = of[k];
+          } else {
+            const int ac = L.acc0 + op.bslot * 27;  // parent's accumulator
+#pragma unroll
+            for (int k = 0; k < 21; ++k) wsst(wsl, ac + k, wsld(wsl, ac + k) + Ia[k]);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) wsst(wsl, ac + 21 + k, wsld(wsl, ac + 21 + k) + of[k]);
+          }
+        }
+      }
+    }
+
+    // ------------------------------------------------ pass 3 (aba.hxx:207-232), forward
+    {
+      double R[9], t[3], ov[6], acc[6];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) R[k] = 0.0;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) t[k] = 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) ov[k] = acc[k] = 0.0;
+      for (int s = 0; s < A.nops3; ++s) {
+        const Op op = load_op(A.prog3, s);
+        JointConst jc;
+      load_joint(A.tab, op.joint, jc);
+        const int fl = op.flags;
+        const bool root = fl & F_PARENT_ROOT;
+        double Rp[9], tp[3], ovp[6], ap[6];
+        if (root) {
+#pragma unroll
+          for (int k = 0; k < 9; ++k) Rp[k] = 0.0;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) tp[k] = 0.0;
+#pragma unroll
+          for (int k = 0; k < 6; ++k) ovp[k] = ap[k] = 0.0;
+          ap[0] = -A.gx; ap[1] = -A.gy; ap[2] = -A.gz;  // aba.hxx:261
+        } else if (fl & F_FROM_REGS) {
+#pragma unroll
+          for (int k = 0; k < 9; ++k) Rp[k] = R[k];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) tp[k] = t[k];
+#pragma unroll
+          for (int k = 0; k < 6; ++k) { ovp[k] = ov[k]; ap[k] = acc[k]; }
+        } else {
+          const int base = L.k30 + op.bslot * 24;
+#pragma unroll
+          for (int k = 0; k < 9; ++k) Rp[k] = wsld(wsl, base + k);
+#pragma unroll
+          for (int k = 0; k < 3; ++k) tp[k] = wsld(wsl, base + 9 + k);
+#pragma unroll
+          for (int k = 0; k < 6; ++k) { ovp[k] = wsld(wsl, base + 12 + k); ap[k] = wsld(wsl, base + 18 + k); }
+        }
+        const int h = L.hand0 + jc.hand_off;
+        double sn = wsld(wsl, h + hand_size(jc.nvj) - 2);
+        double cs = wsld(wsl, h + hand_size(jc.nvj) - 1);
+        double bias[6];
+        aba_kin<LAYOUT>(jc, q, vin, root, true, sn, cs, Rp, tp, ovp, R, t, ov, bias);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) acc[k] = ap[k] + bias[k];  // :223 (oa_gf[i] += oa_gf[parent])
+        const int iv = jc.idx_v;
+        const bool leaf = fl & F_LEAF;
+        if (jc.nvj == 1) {
+          double dd;
+          if (root) {
+            dd = ddq.get(iv);  // written by the backward visit of this lane
+          } else {
+            double UD[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) UD[k] = wsld(wsl, h + k);
+            dd = wsld(wsl, h + 6) - dot6(UD, acc);  // :224-226
+            if (valid) ddq.put(iv, dd);
+          }
+          if (!leaf) {
+            double J[6];
+            jcol_1dof(jc, R, t, J);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) acc[k] += J[k] * dd;  // :227
+          }
+        } else if (jc.nvj == 6) {
+          double dd[6], J[36];
+          if (root) {
+#pragma unroll
+            for (int r = 0; r < 6; ++r) dd[r] = ddq.get(iv + r);
+          } else {
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+              double sum = 0.0;
+#pragma unroll
+              for (int c = 0; c < 6; ++c) sum += wsld(wsl, h + 36 + 6 * r + c) * wsld(wsl, h + 72 + c);
+#pragma unroll
+              for (int k = 0; k < 6; ++k) sum -= wsld(wsl, h + 6 * r + k) * acc[k];
+              dd[r] = sum;
+              if (valid) ddq.put(iv + r, sum);
+            }
+          }
+          jcols_multi<6>(R, t, J);
+#pragma unroll
+          for (int c = 0; c < 6; ++c)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) acc[k] += J[6 * c + k] * dd[c];
+        } else {
+          double dd[3], J[18];
+          if (root) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) dd[r] = ddq.get(iv + r);
+          } else {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+              double sum = 0.0;
+#pragma unroll
+              for (int c = 0; c < 3; ++c) sum += wsld(wsl, h + 18 + 3 * r + c) * wsld(wsl, h + 27 + c);
+#pragma unroll
+              for (int k = 0; k < 6; ++k) sum -= wsld(wsl, h + 6 * r + k) * acc[k];
+              dd[r] = sum;
+              if (valid) ddq.put(iv + r, sum);
+            }
+          }
+          jcols_multi<3>(R, t, J);
+#pragma unroll
+          for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) acc[k] += J[6 * c + k] * dd[c];
+        }
+        if (fl & F_PUSH_BRANCH) {
+          const int base = L.k30 + op_own_bslot(fl) * 24;
+#pragma unroll
+          for (int k = 0; k < 9; ++k) wsst(wsl, base + k, R[k]);
+#pragma unroll
+          for (int k = 0; k < 3; ++k) wsst(wsl, base + 9 + k, t[k]);
+#pragma unroll
+          for (int k = 0; k < 6; ++k) { wsst(wsl, base + 12 + k, ov[k]); wsst(wsl, base + 18 + k, acc[k]); }
+        }
+      }
+    }
+  }
+}
+
+// =================================================================================== FK + Jacobians
+// forwardKinematics(q) (kinematics.hxx:52-97) + computeJointJacobians(q) (jacobian.hxx:38-95).
+// workspace: KB[bslot][12] = oMi of branching joints.  Chains (arms) never touch the workspace.
+template <int LAYOUT>
+__global__ __launch_bounds__(WAVE) void fkjac_kernel(const KArgs A) {
+  const int lane = threadIdx.x;
+  double* const wsl = A.ws + (int64_t)blockIdx.x * A.ws_stride + lane;
+  for (int64_t tile = blockIdx.x; tile < A.ntiles; tile += gridDim.x) {
+    const int64_t b0 = tile * WAVE + lane;
+    const bool valid = b0 < A.B;
+    const int64_t b = valid ? b0 : A.B - 1;
+    const Mat<LAYOUT> q{const_cast<double*>(A.q), A.ldq, b};
+    const Mat<LAYOUT> Jout{A.out, A.ldout, b};
+    const Mat<LAYOUT> Mout{A.out2, A.ldout2, b};
+    const bool wantJ = A.out != nullptr, wantM = A.out2 != nullptr;
+    if (wantM && valid) {  // joint 0 = identity
+#pragma unroll
+      for (int k = 0; k < 12; ++k) Mout.put(k, (k == 0 || k == 4 || k == 8) ? 1.0 : 0.0);
+    }
+    double R[9], t[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) t[k] = 0.0;
+    for (int s = 0; s < A.nops3; ++s) {
+      const Op op = load_op(A.prog3, s);
+      JointConst jc;
+      load_joint(A.tab, op.joint, jc);
+      const int fl = op.flags;
+      const bool root = fl & F_PARENT_ROOT;
+      double Rl[9], tl[3], sn, cs;
+      joint_liMi<LAYOUT>(jc, q, false, sn, cs, Rl, tl);
+      if (root) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) R[k] = Rl[k];
+        t[0] = tl[0]; t[1] = tl[1]; t[2] = tl[2];
+      } else {
+        double Rp[9], tp[3], Rt[3];
+        if (fl & F_FROM_REGS) {
+#pragma unroll
+          for (int k = 0; k < 9; ++k) Rp[k] = R[k];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) tp[k] = t[k];
+        } else {
+          const int base = op.bslot * 12;
+#pragma unroll
+          for (int k = 0; k < 9; ++k) Rp[k] = wsld(wsl, base + k);
+#pragma unroll
+          for (int k = 0; k < 3; ++k) tp[k] = wsld(wsl, base + 9 + k);
+        }
+        rot_mul(Rp, Rl, R);
+        rot_vec(Rp, tl, Rt);
+        t[0] = tp[0] + Rt[0]; t[1] = tp[1] + Rt[1]; t[2] = tp[2] + Rt[2];
+      }
+      if (fl & F_PUSH_BRANCH) {
+        const int base = op_own_bslot(fl) * 12;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wsst(wsl, base + k, R[k]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) wsst(wsl, base + 9 + k, t[k]);
+      }
+      if (wantM && valid) {
+        const int o = 12 * op.joint;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) Mout.put(o + 3 * c + r, R[3 * r + c]);  // column-major rotation
+        Mout.put(o + 9, t[0]); Mout.put(o + 10, t[1]); Mout.put(o + 11, t[2]);
+      }
+      if (wantJ && valid) {
+        const int o = 6 * jc.idx_v;
+        if (jc.nvj == 1) {
+          double J[6];
+          jcol_1dof(jc, R, t, J);
+#pragma unroll
+          for (int k = 0; k < 6; ++k) Jout.put(o + k, J[k]);
+        } else if (jc.nvj == 6) {
+          double J[36];
+          jcols_multi<6>(R, t, J);
+#pragma unroll
+          for (int k = 0; k < 36; ++k) Jout.put(o + k, J[k]);
+        } else {
+          double J[18];
+          jcols_multi<3>(R, t, J);
+#pragma unroll
+          for (int k = 0; k < 18; ++k) Jout.put(o + k, J[k]);
+        }
+      }
+    }
+  }
+}
+
+// =================================================================================== layout helpers
+// dof x B instance-major (x[b*ld + d]) <-> batch-major (y[d*ld + b]) through a padded LDS tile.
+__global__ __launch_bounds__(256) void transpose_kernel(const double* __restrict__ src, int64_t ld_src,
+                                                        double* __restrict__ dst, int64_t ld_dst,
+                                                        int64_t dof, int64_t B, int to_batch_major) {
+  __shared__ double tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int64_t b0 = (int64_t)blockIdx.x * 32, d0 = (int64_t)blockIdx.y * 32;
+  if (to_batch_major) {
+    // read rows of instances (contiguous in d), write rows of dofs (contiguous in b)
+    for (int i = ty; i < 32; i += 8) {
+      const int64_t b = b0 + i, d = d0 + tx;
+      if (b < B && d < dof) tile[i][tx] = src[b * ld_src + d];
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+      const int64_t d = d0 + i, b = b0 + tx;
+      if (b < B && d < dof) dst[d * ld_dst + b] = tile[tx][i];
+    }
+  } else {
+    for (int i = ty; i < 32; i += 8) {
+      const int64_t d = d0 + i, b = b0 + tx;
+      if (b < B && d < dof) tile[i][tx] = src[d * ld_src + b];
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+      const int64_t b = b0 + i, d = d0 + tx;
+      if (b < B && d < dof) dst[b * ld_dst + d] = tile[tx][i];
+    }
+  }
+}
+
+}  // namespace brbd

@@ -1131,7 +1131,12 @@ int brbd_oracle_rnea_derivatives(const brbd_model_desc* m, const double* q, cons
 
 int brbd_oracle_max_threads(void) {
 #ifdef _OPENMP
-  return omp_get_max_threads();
+  /* the batch loops call omp_set_num_threads() like the reference
+   * (utils/openmp.hpp:31-35), which changes omp_get_max_threads(): remember the
+   * value the process started with (OMP_NUM_THREADS or the core count) */
+  static int initial = 0;
+  if (initial == 0) initial = omp_get_max_threads();
+  return initial;
 #else
   return 1;
 #endif

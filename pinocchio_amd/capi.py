@@ -66,6 +66,14 @@ def lib():
         raise BrbdLibraryError(
             f"{LIB_PATH} not found: build it with `make -C pinocchio_amd/csrc` "
             "(or `python -c 'import __graft_entry__ as g; g.build()'`); the engine has no CPU fallback")
+    # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64.so (SONAME
+    # libamdhip64.so.7, same as /opt/rocm's).  Load torch FIRST so that our library's
+    # DT_NEEDED libamdhip64.so.7 resolves to the runtime torch uses; otherwise two runtimes
+    # coexist, device pointers / streams cannot be shared and the second one sees no device.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch-less deployment uses /opt/rocm's runtime
+        pass
     try:
         L = ctypes.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover

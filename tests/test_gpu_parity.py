@@ -1,0 +1,298 @@
+"""Parity tests proper: the HIP path, called through the C ABI (pinocchio_amd.capi /
+pinocchio_amd.parallel are thin ctypes plumbing over include/brbd.h), against the CPU oracle on
+the same seeded inputs, against the committed golden vectors, and -- at BASELINE.json's full
+sizes -- through size-independent properties.
+
+Tolerances (north_star: <= 1e-10 relative in fp64), Eigen isApprox semantics per instance
+(||x - y|| <= tol * min(||x||, ||y||), as in the reference's tests):
+  RNEA 1e-12, FK / Jacobians 1e-12 (absolute, entries are O(1)), ABA 1e-10, RNEA derivatives 1e-10.
+"""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from pinocchio_amd import capi, model as M, parallel, sample_models as S
+from util import inputs, parity_models, rel_err_cols
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+MODELS = parity_models()
+IDS = [m.name for m in MODELS]
+TOL_RNEA, TOL_KIN, TOL_ABA, TOL_DERIV = 1e-12, 1e-12, 1e-10, 1e-10
+
+
+def _mat_rel(x, y):
+    return np.abs(x - y).max() / max(1.0, np.abs(y).max())
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a device"
+    return torch
+
+
+@pytest.mark.parametrize("order", ["F", "C"])
+@pytest.mark.parametrize("model", MODELS, ids=IDS)
+def test_all_algorithms_vs_oracle_host_memspace(model, order):
+    """Host pointers (the reference's calling convention) in both boundary layouts; B = 200 is
+    ragged (3 full waves + 8 lanes)."""
+    pool = parallel.ModelPool(model, 1)
+    O = oracle.Oracle(model)
+    q, v, a = inputs(model, 200, 11)
+    qq, vv, aa = (np.asarray(x, order=order) for x in (q, v, a))
+    tau_ref = O.rnea(q, v, a)
+    tau = parallel.rneaInParallel(1, pool, qq, vv, aa)
+    assert tau.flags["F_CONTIGUOUS" if order == "F" else "C_CONTIGUOUS"]
+    assert rel_err_cols(tau, tau_ref).max() < TOL_RNEA
+    ddq = parallel.abaInParallel(1, pool, qq, vv, np.asarray(tau_ref, order=order))
+    assert rel_err_cols(ddq, O.aba(q, v, tau_ref)).max() < TOL_ABA
+    assert rel_err_cols(ddq, a).max() < TOL_ABA  # unittest/aba.cpp:143-154
+    J, oMi = parallel.computeJointJacobians(pool, qq, want_oMi=True)
+    Jr, Mr = O.fk_jacobians(q)
+    assert np.abs(J - Jr).max() < TOL_KIN and np.abs(oMi - Mr).max() < TOL_KIN
+    assert np.abs(parallel.forwardKinematics(pool, qq) - Mr).max() < TOL_KIN
+    if model.is_depth_first():
+        dq, dv, da, tau2 = parallel.computeRNEADerivatives(pool, qq, vv, aa, want_tau=True)
+        rq, rv, ra, _ = O.rnea_derivatives(q, v, a)
+        assert _mat_rel(dq, rq) < TOL_DERIV and _mat_rel(dv, rv) < TOL_DERIV and _mat_rel(da, ra) < TOL_DERIV
+        assert rel_err_cols(tau2, tau_ref).max() < TOL_RNEA
+    pool.release()
+
+
+@pytest.mark.parametrize("name", ["simple_humanoid", "manipulator", "arm7", "quadruped", "talos_like", "baxter_simple"])
+def test_golden_vectors(name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    pool = parallel.ModelPool(S.build(name), 1)
+    assert rel_err_cols(parallel.rneaInParallel(1, pool, g["q"], g["v"], g["a"]), g["tau"]).max() < TOL_RNEA
+    assert rel_err_cols(parallel.abaInParallel(1, pool, g["q"], g["v"], g["tau"]), g["ddq"]).max() < TOL_ABA
+    J, oMi = parallel.computeJointJacobians(pool, g["q"], want_oMi=True)
+    assert np.abs(J - g["J"]).max() < TOL_KIN and np.abs(oMi - g["oMi"]).max() < TOL_KIN
+    if "dtau_dq" in g:
+        dq, dv, da = parallel.computeRNEADerivatives(pool, g["q"], g["v"], g["a"])
+        assert _mat_rel(dq, g["dtau_dq"]) < TOL_DERIV
+        assert _mat_rel(dv, g["dtau_dv"]) < TOL_DERIV
+        assert _mat_rel(da, g["dtau_da"]) < TOL_DERIV
+    pool.release()
+
+
+@pytest.mark.parametrize("B", [1, 63, 64, 65, 129])
+def test_ragged_batches(B):
+    model = S.quadruped()
+    pool = parallel.ModelPool(model, 1)
+    O = oracle.Oracle(model)
+    q, v, a = inputs(model, B, B)
+    tau = parallel.rneaInParallel(1, pool, q, v, a)
+    assert tau.shape == (model.nv, B)
+    assert rel_err_cols(tau, O.rnea(q, v, a)).max() < TOL_RNEA
+    assert rel_err_cols(parallel.abaInParallel(1, pool, q, v, tau), a).max() < TOL_ABA
+    pool.release()
+
+
+def test_empty_batch():
+    model = S.manipulator()
+    pool = parallel.ModelPool(model, 1)
+    z = np.zeros((6, 0))
+    assert parallel.rneaInParallel(1, pool, z, z, z).shape == (6, 0)
+    assert parallel.abaInParallel(1, pool, z, z, z).shape == (6, 0)
+    pool.release()
+
+
+def test_in_place_overloads_and_mixed_orders():
+    """pin.rneaInParallel(n, pool, q, v, a, tau) / abaInParallel(..., a) write the caller's array
+    (bindings/python/algorithm/parallel/rnea.cpp:44-63)."""
+    model = S.arm7()
+    pool = parallel.ModelPool(model, 2)
+    O = oracle.Oracle(model)
+    q, v, a = inputs(model, 40, 3)
+    tau = np.full((model.nv, 40), np.nan, order="F")
+    ret = parallel.rneaInParallel(2, pool, q, np.ascontiguousarray(v), a, tau)
+    assert ret is tau and rel_err_cols(tau, O.rnea(q, v, a)).max() < TOL_RNEA
+    out_c = np.full((model.nv, 40), np.nan)  # C-ordered output next to Fortran-ordered inputs
+    parallel.abaInParallel(1, pool, q, v, tau, out_c)
+    assert rel_err_cols(out_c, a).max() < TOL_ABA
+    pool.release()
+
+
+@pytest.mark.parametrize("layout", ["batch_major", "instance_major"])
+def test_device_memspace_with_padding(torch_mod, layout):
+    """Device-resident tensors, used in place, with leading dimensions larger than needed."""
+    torch = torch_mod
+    model = S.simple_humanoid()
+    pool = parallel.ModelPool(model, 1)
+    O = oracle.Oracle(model)
+    B, pad = 300, 17
+    q, v, a = inputs(model, B, 5)
+    dev = torch.device("cuda", 0)
+
+    def put(x):
+        rows = x.shape[0]
+        if layout == "batch_major":
+            big = torch.full((rows, B + pad), float("nan"), dtype=torch.float64, device=dev)
+            big[:, :B] = torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+            return big, big[:, :B]
+        big = torch.full((B, rows + pad), float("nan"), dtype=torch.float64, device=dev)
+        big[:, :rows] = torch.from_numpy(np.ascontiguousarray(x.T)).to(dev)
+        return big, big[:, :rows].t()
+
+    (_, qd), (_, vd), (_, ad) = put(q), put(v), put(a)
+    big_t, tau = put(np.zeros((model.nv, B)))
+    parallel.rneaInParallel(1, pool, qd, vd, ad, tau)
+    torch.cuda.synchronize()
+    assert rel_err_cols(tau.cpu().numpy(), O.rnea(q, v, a)).max() < TOL_RNEA
+    # padding untouched
+    if layout == "batch_major":
+        assert torch.isnan(big_t[:, B:]).all()
+    else:
+        assert torch.isnan(big_t[:, model.nv:]).all()
+    ddq = parallel.abaInParallel(1, pool, qd, vd, tau)
+    torch.cuda.synchronize()
+    assert rel_err_cols(ddq.cpu().numpy(), a).max() < TOL_ABA
+    pool.release()
+
+
+def test_full_size_headline_properties(torch_mod):
+    """BASELINE.json configs[2] size (simple_humanoid, batch 65536): size-independent properties.
+    (1) aba(q, v, rnea(q, v, a)) == a per instance (unittest/aba.cpp:143-154);
+    (2) rnea is affine in a: rnea(a1 + a2) - rnea(a1) - rnea(a2) + rnea(0) == 0 (rnea.cpp:198-206);
+    (3) 256 randomly chosen instances match the oracle; (4) relaunch is bitwise reproducible."""
+    torch = torch_mod
+    model = S.simple_humanoid()
+    pool = parallel.ModelPool(model, 1)
+    B = 65536
+    q, v, a = inputs(model, B, 65536)
+    dev = torch.device("cuda", 0)
+    qd, vd, ad = (torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (q, v, a))
+    tau = parallel.rneaInParallel(1, pool, qd, vd, ad)
+    ddq = parallel.abaInParallel(1, pool, qd, vd, tau)
+    err = ((ddq - ad).norm(dim=0) / ad.norm(dim=0)).max().item()
+    assert err < TOL_ABA, err
+    a2 = torch.flip(ad, dims=[1])
+    lin = (parallel.rneaInParallel(1, pool, qd, vd, ad + a2) - tau
+           - parallel.rneaInParallel(1, pool, qd, vd, a2) + parallel.rneaInParallel(1, pool, qd, vd, 0 * ad))
+    assert (lin.norm(dim=0) / tau.norm(dim=0)).max().item() < 1e-12
+    idx = np.random.default_rng(0).choice(B, 256, replace=False)
+    O = oracle.Oracle(model)
+    tr = O.rnea(q[:, idx], v[:, idx], a[:, idx], threads=0)
+    assert rel_err_cols(tau[:, idx].cpu().numpy(), tr).max() < TOL_RNEA
+    assert rel_err_cols(ddq[:, idx].cpu().numpy(), O.aba(q[:, idx], v[:, idx], tr, threads=0)).max() < TOL_ABA
+    assert torch.equal(parallel.abaInParallel(1, pool, qd, vd, tau), ddq)
+    pool.release()
+
+
+def test_full_size_fk_jacobians_arm(torch_mod):
+    """BASELINE.json configs[1]: 7-dof arm FK + Jacobians, batch 1M: more tiles than resident
+    waves (grid-stride path).  Properties: J columns are unit twists (|angular| == 1), the
+    rotation of every oMi is orthonormal; 128 sampled instances match the oracle."""
+    torch = torch_mod
+    model = S.arm7()
+    pool = parallel.ModelPool(model, 1)
+    B = 1 << 20
+    rng = np.random.default_rng(1)
+    q = rng.uniform(-1, 1, (model.nq, B))
+    qd = torch.from_numpy(q).to("cuda:0")
+    J, oMi = parallel.computeJointJacobians(pool, qd, want_oMi=True)
+    Jv = J.view(model.nv, 6, B)
+    assert (Jv[:, 3:, :].norm(dim=1) - 1).abs().max().item() < 1e-13
+    Rm = oMi.view(model.njoints, 12, B)[1:, :9, :].reshape(-1, 3, 3, B)  # column-major: [col][row]
+    gram = torch.einsum("jcrb,jdrb->jcdb", Rm, Rm)
+    eye = torch.eye(3, dtype=torch.float64, device=gram.device)[None, :, :, None]
+    assert (gram - eye).abs().max().item() < 1e-13
+    idx = rng.choice(B, 128, replace=False)
+    Jr, Mr = oracle.Oracle(model).fk_jacobians(q[:, idx])
+    assert np.abs(J[:, idx].cpu().numpy() - Jr).max() < TOL_KIN
+    assert np.abs(oMi[:, idx].cpu().numpy() - Mr).max() < TOL_KIN
+    pool.release()
+
+
+def test_derivatives_vs_finite_differences_on_device(torch_mod):
+    """unittest/rnea-derivatives.cpp:158-303 through the HIP path only: dtau/dv by forward
+    differences of the HIP RNEA (alpha = 1e-8, tolerance sqrt(alpha)); dtau/da symmetric upper
+    triangle == M built from HIP RNEA columns (:293-299)."""
+    model = S.quadruped()
+    pool = parallel.ModelPool(model, 1)
+    nv = model.nv
+    q, v, a = inputs(model, 1, 9)
+    dq, dv, da = parallel.computeRNEADerivatives(pool, q, v, a)
+    dv, da = dv[:, 0].reshape(nv, nv).T, da[:, 0].reshape(nv, nv).T
+    alpha = 1e-8
+    Q = np.repeat(q, nv, axis=1)
+    V = np.repeat(v, nv, axis=1) + alpha * np.eye(nv)
+    Aa = np.repeat(a, nv, axis=1)
+    tau0 = parallel.rneaInParallel(1, pool, q, v, a)
+    fdv = (parallel.rneaInParallel(1, pool, np.asfortranarray(Q), np.asfortranarray(V), np.asfortranarray(Aa)) - tau0) / alpha
+    assert np.linalg.norm(dv - fdv) < np.sqrt(alpha) * max(1.0, np.linalg.norm(fdv))
+    Z = np.zeros((nv, nv), order="F")
+    Mm = (parallel.rneaInParallel(1, pool, np.asfortranarray(Q), Z, np.asfortranarray(np.eye(nv)))
+          - parallel.rneaInParallel(1, pool, np.asfortranarray(Q), Z, Z))
+    assert np.abs(np.triu(da) - np.triu(Mm)).max() < 1e-11 * max(1.0, np.abs(Mm).max())
+    pool.release()
+
+
+def test_c_abi_error_codes(torch_mod):
+    torch = torch_mod
+    L = capi.lib()
+    model = S.manipulator()
+    dm = capi.DeviceModel(model, 0)
+    x = torch.zeros((6, 8), dtype=torch.float64, device="cuda:0")
+    p = x.data_ptr()
+    # NULL pointer / too-small leading dimension / bad layout -> INVALID_ARGUMENT, nothing launched
+    assert L.brbd_rnea(dm.handle, 8, None, 8, p, 8, p, 8, p, 8, capi.BATCH_MAJOR, capi.DEVICE, None) == capi.BRBD_ERR_INVALID_ARGUMENT
+    assert "q is NULL" in capi.last_error()
+    assert L.brbd_rnea(dm.handle, 8, p, 4, p, 8, p, 8, p, 8, capi.BATCH_MAJOR, capi.DEVICE, None) == capi.BRBD_ERR_INVALID_ARGUMENT
+    assert L.brbd_aba(dm.handle, 8, p, 8, p, 8, p, 3, p, 8, capi.BATCH_MAJOR, capi.DEVICE, None) == capi.BRBD_ERR_INVALID_ARGUMENT
+    assert "tau" in capi.last_error()
+    assert L.brbd_rnea(dm.handle, 8, p, 8, p, 8, p, 8, p, 8, 7, capi.DEVICE, None) == capi.BRBD_ERR_INVALID_ARGUMENT
+    assert L.brbd_rnea(dm.handle, -1, p, 8, p, 8, p, 8, p, 8, capi.BATCH_MAJOR, capi.DEVICE, None) == capi.BRBD_ERR_INVALID_ARGUMENT
+    assert L.brbd_model_create(ctypes.byref(model.to_desc()[0]), 99, ctypes.byref(ctypes.c_void_p())) == capi.BRBD_ERR_INVALID_ARGUMENT
+    assert dm.workspace_bytes(capi.ALGO_ABA, 65536) > 0
+    dm.close()
+    # RNEA derivatives need depth-first numbering (Data::computeNvSubtree, data.hxx:205-230)
+    m = M.Model("not_dfs")
+    j1 = m.addJoint(0, M.JOINT_RX, np.eye(4), "a")
+    j2 = m.addJoint(0, M.JOINT_RY, np.eye(4), "b")
+    j3 = m.addJoint(j1, M.JOINT_RZ, np.eye(4), "c")
+    for j in (j1, j2, j3):
+        m.appendBodyToJoint(j, M.Inertia(1.0, [0.1, 0, 0], np.eye(3)))
+    assert not m.is_depth_first()
+    pool = parallel.ModelPool(m, 1)
+    z = np.zeros((3, 4))
+    with pytest.raises(capi.BrbdUnsupported):
+        parallel.computeRNEADerivatives(pool, z, z, z)
+    # ...while RNEA / ABA handle any parents[i] < i ordering
+    O = oracle.Oracle(m)
+    q, v, a = inputs(m, 32, 2)
+    tau = parallel.rneaInParallel(1, pool, q, v, a)
+    assert rel_err_cols(tau, O.rnea(q, v, a)).max() < TOL_RNEA
+    assert rel_err_cols(parallel.abaInParallel(1, pool, q, v, tau), a).max() < TOL_ABA
+    pool.release()
+
+
+def test_transposes_and_kernel_timing(torch_mod):
+    torch = torch_mod
+    L = capi.lib()
+    dof, B = 37, 1000
+    x = torch.randn((B, dof), dtype=torch.float64, device="cuda:0")  # instance-major
+    y = torch.empty((dof, B), dtype=torch.float64, device="cuda:0")
+    z = torch.empty_like(x)
+    capi.check(L.brbd_transpose_to_batch_major(0, dof, B, x.data_ptr(), dof, y.data_ptr(), B, None))
+    capi.check(L.brbd_transpose_to_instance_major(0, dof, B, y.data_ptr(), B, z.data_ptr(), dof, None))
+    torch.cuda.synchronize()
+    assert torch.equal(y, x.t()) and torch.equal(z, x)
+    model = S.quadruped()
+    pool = parallel.ModelPool(model, 1)
+    dm = pool.device_model(0)
+    q, v, a = inputs(model, 4096, 1)
+    qd, vd, ad = (torch.from_numpy(np.ascontiguousarray(t)).to("cuda:0") for t in (q, v, a))
+    dm.set_timing(True)
+    for _ in range(3):
+        parallel.rneaInParallel(1, pool, qd, vd, ad)
+    n, ms = dm.kernel_time(capi.ALGO_RNEA)
+    dm.set_timing(False)
+    assert n == 3 and 0 < ms < 1000
+    assert dm.kernel_time(capi.ALGO_RNEA) == (0, 0.0)
+    pool.release()

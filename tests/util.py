@@ -24,7 +24,7 @@ def inputs(model, B, seed=0):
     return q, v, a
 
 
-def test_models():
+def parity_models():
     """Models every parity test runs on: the built-ins + random trees over all kernel-supported
     joint kinds, with and without free-flyer root / armature, including multi-root forests."""
     kinds = [M.JOINT_RX, M.JOINT_RY, M.JOINT_RZ, M.JOINT_PX, M.JOINT_PY, M.JOINT_PZ, M.JOINT_SPHERICAL,

@@ -4,7 +4,7 @@ import numpy as np
 from pinocchio_amd import capi, parallel, sample_models as S
 import oracle
 sys.path.insert(0,os.path.join(ROOT,'tests'))
-from util import rel_err_cols, inputs, test_models
+from util import rel_err_cols, inputs, parity_models as test_models
 print("devices", capi.lib().brbd_device_count(), flush=True)
 for m in test_models():
     pool = parallel.ModelPool(m, 1)

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -17,6 +18,7 @@
 #include "brbd_flatten.hpp"
 #include "brbd_kernels.hpp"
 #include "brbd_deriv.hpp"
+#include "brbd_static.hpp"
 
 using namespace brbd;
 
@@ -57,6 +59,9 @@ struct brbd_model {
   size_t stage_doubles = 0;
   // per-algorithm launch geometry (waves resident on the device)
   int max_waves[4] = {0, 0, 0, 0};
+  int max_waves_static[4] = {0, 0, 0, 0};
+  const StaticEntry* stat = nullptr;  // unrolled kernels for this topology, if registered
+  bool use_static = true;
   bool timing = false;
   std::vector<TimedLaunch> timed[4];
   std::mutex mu;
@@ -171,14 +176,23 @@ int launch_algo(brbd_model* m, int algo, KArgs& A, int layout, hipStream_t strea
     case BRBD_ALGO_FK_JAC: per_lane = F.ws_fkjac(); break;
     default: return fail(BRBD_ERR_INVALID_ARGUMENT, "unknown algorithm");
   }
-  if (m->max_waves[algo] == 0) {
+  const bool stat = m->stat && m->use_static && layout == BRBD_BATCH_MAJOR;
+  KernelFn sfn = nullptr;
+  if (stat) {
+    sfn = algo == BRBD_ALGO_RNEA ? m->stat->rnea : (algo == BRBD_ALGO_ABA ? m->stat->aba : m->stat->fkjac);
+    // the unrolled kernels keep the path state in registers: only ABA's hand-off records spill
+    per_lane = algo == BRBD_ALGO_ABA ? F.hand_total : 1;
+  }
+  int& mw = stat ? m->max_waves_static[algo] : m->max_waves[algo];
+  if (mw == 0) {
     int w = 0;
-    if (algo == BRBD_ALGO_RNEA) w = resident_waves(m, rnea_kernel<1>, WAVE);
+    if (stat) w = resident_waves(m, sfn, WAVE);
+    else if (algo == BRBD_ALGO_RNEA) w = resident_waves(m, rnea_kernel<1>, WAVE);
     else if (algo == BRBD_ALGO_ABA) w = resident_waves(m, aba_kernel<1>, WAVE);
     else w = resident_waves(m, fkjac_kernel<1>, WAVE);
-    m->max_waves[algo] = w;
+    mw = w;
   }
-  int64_t grid = A.ntiles < m->max_waves[algo] ? A.ntiles : m->max_waves[algo];
+  int64_t grid = A.ntiles < mw ? A.ntiles : mw;
   A.ws_stride = (int64_t)per_lane * WAVE;
   int rc = ensure_ws(m, (size_t)grid * A.ws_stride);
   if (rc) return rc;
@@ -186,7 +200,9 @@ int launch_algo(brbd_model* m, int algo, KArgs& A, int layout, hipStream_t strea
   Timer tm{m, algo, stream};
   if ((rc = tm.begin())) return rc;
   const dim3 g((unsigned)grid), b(WAVE);
-  if (algo == BRBD_ALGO_RNEA) {
+  if (stat) {
+    hipLaunchKernelGGL(sfn, g, b, 0, stream, A);
+  } else if (algo == BRBD_ALGO_RNEA) {
     if (layout == BRBD_BATCH_MAJOR) hipLaunchKernelGGL(rnea_kernel<1>, g, b, 0, stream, A);
     else hipLaunchKernelGGL(rnea_kernel<0>, g, b, 0, stream, A);
   } else if (algo == BRBD_ALGO_ABA) {
@@ -248,6 +264,23 @@ int brbd_model_create(const brbd_model_desc* desc, int device, brbd_model** out)
     return fail(BRBD_ERR_RUNTIME, "hipGetDeviceProperties failed");
   }
   m->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  {
+    // select the unrolled kernels iff a registered topology has exactly this program
+    int cnt = 0;
+    const StaticEntry* reg = static_registry(&cnt);
+    for (int k = 0; k < cnt; ++k) {
+      const StaticEntry& e = reg[k];
+      if (e.njoints != F.njoints || e.nq != F.nq || e.nv != F.nv || e.nops != (int)F.prog.size() ||
+          e.nops3 != (int)F.prog3.size() || e.hand_total != F.hand_total)
+        continue;
+      if (std::memcmp(e.prog, F.prog.data(), sizeof(Op) * F.prog.size()) != 0) continue;
+      if (std::memcmp(e.prog3, F.prog3.data(), sizeof(Op) * F.prog3.size()) != 0) continue;
+      m->stat = &e;
+      break;
+    }
+    const char* env = getenv("BRBD_DISABLE_STATIC");
+    if (env && env[0] == '1') m->use_static = false;
+  }
   auto upload = [&](void** dst, const void* src, size_t bytes) -> hipError_t {
     hipError_t e = hipMalloc(dst, bytes ? bytes : 16);
     if (e != hipSuccess) return e;
@@ -533,6 +566,16 @@ int brbd_transpose_to_batch_major(int device, int64_t dof, int64_t B, const doub
 int brbd_transpose_to_instance_major(int device, int64_t dof, int64_t B, const double* src,
                                      int64_t ld_src, double* dst, int64_t ld_dst, void* stream) {
   return transpose_common(device, dof, B, src, ld_src, dst, ld_dst, stream, 0);
+}
+
+const char* brbd_model_static_topology(const brbd_model* m) {
+  return (m && m->stat) ? m->stat->name : "";
+}
+
+int brbd_model_use_static(brbd_model* m, int enabled) {
+  if (!m) return fail(BRBD_ERR_INVALID_ARGUMENT, "model handle is NULL");
+  m->use_static = enabled != 0;
+  return BRBD_OK;
 }
 
 int brbd_set_timing(brbd_model* m, int enabled) {

@@ -35,13 +35,13 @@ enum { DC_J = 0, DC_DVDQ, DC_DADQ, DC_DADV, DC_DFDA, DC_DFDQ, DC_DFDV, DC_DYTJ, 
 
 inline int deriv_ws_per_lane(const FlatModel& F) { return DC_COUNT * 6 * F.nv + DJ_SIZE * F.njoints; }
 
-DI void ld6(const double* w, int slot, double* o) {
+DI void ld6(const GlobalStore& w, int slot, double* o) {
 #pragma unroll
-  for (int k = 0; k < 6; ++k) o[k] = wsld(w, slot + k);
+  for (int k = 0; k < 6; ++k) o[k] = w.ld(slot + k);
 }
-DI void st6(double* w, int slot, const double* x) {
+DI void st6(const GlobalStore& w, int slot, const double* x) {
 #pragma unroll
-  for (int k = 0; k < 6; ++k) wsst(w, slot + k, x[k]);
+  for (int k = 0; k < 6; ++k) w.st(slot + k, x[k]);
 }
 DI void skew3(const double* v, double* S) {
   S[0] = 0; S[1] = -v[2]; S[2] = v[1];
@@ -107,22 +107,20 @@ DI void mat6_mulvec(const double* M, const double* x, double* o) {
 template <int LAYOUT>
 __global__ __launch_bounds__(WAVE) void rnea_deriv_kernel(const DerivArgs A) {
   const int lane = threadIdx.x;
-  double* const wsl = A.ws + (int64_t)blockIdx.x * A.ws_stride + lane;
+  const GlobalStore W(A.ws + (int64_t)blockIdx.x * A.ws_stride, (unsigned)lane);
   const int nv = A.nv, n = A.njoints;
   const int colsz = 6 * nv;
   const int J0 = 0;  // column block b starts at b * colsz
   const int JR0 = DC_COUNT * colsz;
   for (int64_t tile = blockIdx.x; tile < A.ntiles; tile += gridDim.x) {
-    const int64_t b0 = tile * WAVE + lane;
-    const bool valid = b0 < A.B;
-    const int64_t b = valid ? b0 : A.B - 1;
-    const Mat<LAYOUT> q{const_cast<double*>(A.q), A.ldq, b};
-    const Mat<LAYOUT> vin{const_cast<double*>(A.v), A.ldv, b};
-    const Mat<LAYOUT> ain{const_cast<double*>(A.a), A.lda, b};
-    const Mat<LAYOUT> pdq{A.dq, A.lddq, b};
-    const Mat<LAYOUT> pdv{A.dv, A.lddv, b};
-    const Mat<LAYOUT> pda{A.da, A.ldda, b};
-    const Mat<LAYOUT> ptau{A.tau, A.ldtau, b};
+    const bool valid = true;  // lanes past the batch are clamped onto the last instance (Mat)
+    const Mat<LAYOUT> q(const_cast<double*>(A.q), A.ldq, tile, A.B, lane);
+    const Mat<LAYOUT> vin(const_cast<double*>(A.v), A.ldv, tile, A.B, lane);
+    const Mat<LAYOUT> ain(const_cast<double*>(A.a), A.lda, tile, A.B, lane);
+    const Mat<LAYOUT> pdq(A.dq, A.lddq, tile, A.B, lane);
+    const Mat<LAYOUT> pdv(A.dv, A.lddv, tile, A.B, lane);
+    const Mat<LAYOUT> pda(A.da, A.ldda, tile, A.B, lane);
+    const Mat<LAYOUT> ptau(A.tau, A.ldtau, tile, A.B, lane);
     const bool wantM = A.da != nullptr, wantTau = A.tau != nullptr;
     // structural zeros (the reference asks the caller to pre-zero, rnea-derivatives.hpp:104-106)
     if (valid)
@@ -139,22 +137,23 @@ __global__ __launch_bounds__(WAVE) void rnea_deriv_kernel(const DerivArgs A) {
       const int p = jc.parent, iv = jc.idx_v, nvj = jc.nvj;
       const int rec = JR0 + DJ_SIZE * i, prec = JR0 + DJ_SIZE * p;
       double Rl[9], tl[3], sn, cs, R[9], t[3];
-      joint_liMi<LAYOUT>(jc, q, false, sn, cs, Rl, tl);
+      const Op op = op_from_joint(jc, i);
+      joint_liMi(jc, op, q, false, sn, cs, Rl, tl);
       double vJ[6], Sa[6], vloc[6], aloc[6], tmp[6];
-      joint_S_times<LAYOUT>(jc, vin, vJ);
-      joint_S_times<LAYOUT>(jc, ain, Sa);
+      joint_S_times(op, vin, vJ);
+      joint_S_times(op, ain, Sa);
       double ovp[6], oagfp[6];
       if (p > 0) {
         double Rp[9], tp[3], Rt[3], vp[6], ap[6];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) Rp[k] = wsld(wsl, prec + DJ_OMI + k);
+        for (int k = 0; k < 9; ++k) Rp[k] = W.ld(prec + DJ_OMI + k);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) tp[k] = wsld(wsl, prec + DJ_OMI + 9 + k);
+        for (int k = 0; k < 3; ++k) tp[k] = W.ld(prec + DJ_OMI + 9 + k);
         rot_mul(Rp, Rl, R);
         rot_vec(Rp, tl, Rt);
         t[0] = tp[0] + Rt[0]; t[1] = tp[1] + Rt[1]; t[2] = tp[2] + Rt[2];
-        ld6(wsl, prec + DJ_V, vp);
-        ld6(wsl, prec + DJ_A, ap);
+        ld6(W, prec + DJ_V, vp);
+        ld6(W, prec + DJ_A, ap);
         se3_actinv_motion(Rl, tl, vp, tmp);
 #pragma unroll
         for (int k = 0; k < 6; ++k) vloc[k] = vJ[k] + tmp[k];
@@ -162,8 +161,8 @@ __global__ __launch_bounds__(WAVE) void rnea_deriv_kernel(const DerivArgs A) {
         se3_actinv_motion(Rl, tl, ap, tmp);
 #pragma unroll
         for (int k = 0; k < 6; ++k) aloc[k] = (Sa[k] + aloc[k]) + tmp[k];
-        ld6(wsl, prec + DJ_OV, ovp);
-        ld6(wsl, prec + DJ_OAGF, oagfp);
+        ld6(W, prec + DJ_OV, ovp);
+        ld6(W, prec + DJ_OAGF, oagfp);
       } else {
 #pragma unroll
         for (int k = 0; k < 9; ++k) R[k] = Rl[k];
@@ -176,11 +175,11 @@ __global__ __launch_bounds__(WAVE) void rnea_deriv_kernel(const DerivArgs A) {
         oagfp[0] = -A.gx; oagfp[1] = -A.gy; oagfp[2] = -A.gz;  // :504
       }
 #pragma unroll
-      for (int k = 0; k < 9; ++k) wsst(wsl, rec + DJ_OMI + k, R[k]);
+      for (int k = 0; k < 9; ++k) W.st(rec + DJ_OMI + k, R[k]);
 #pragma unroll
-      for (int k = 0; k < 3; ++k) wsst(wsl, rec + DJ_OMI + 9 + k, t[k]);
-      st6(wsl, rec + DJ_V, vloc);
-      st6(wsl, rec + DJ_A, aloc);
+      for (int k = 0; k < 3; ++k) W.st(rec + DJ_OMI + 9 + k, t[k]);
+      st6(W, rec + DJ_V, vloc);
+      st6(W, rec + DJ_A, aloc);
       double cw[3], Iw[6], ov[6], oa[6], oh[6], of[6];
       inertia_to_world(R, t, jc.m, jc.c, jc.I, cw, Iw);  // :302
       se3_act_motion(R, t, vloc, ov);                    // :303
@@ -191,14 +190,14 @@ __global__ __launch_bounds__(WAVE) void rnea_deriv_kernel(const DerivArgs A) {
       force_cross(ov, oh, tmp);
 #pragma unroll
       for (int k = 0; k < 6; ++k) of[k] += tmp[k];
-      st6(wsl, rec + DJ_OV, ov);
-      st6(wsl, rec + DJ_OAGF, oa);
-      st6(wsl, rec + DJ_OF, of);
-      wsst(wsl, rec + DJ_Y, jc.m);
+      st6(W, rec + DJ_OV, ov);
+      st6(W, rec + DJ_OAGF, oa);
+      st6(W, rec + DJ_OF, of);
+      W.st(rec + DJ_Y, jc.m);
 #pragma unroll
-      for (int k = 0; k < 3; ++k) wsst(wsl, rec + DJ_Y + 1 + k, cw[k]);
+      for (int k = 0; k < 3; ++k) W.st(rec + DJ_Y + 1 + k, cw[k]);
 #pragma unroll
-      for (int k = 0; k < 6; ++k) wsst(wsl, rec + DJ_Y + 4 + k, Iw[k]);
+      for (int k = 0; k < 6; ++k) W.st(rec + DJ_Y + 4 + k, Iw[k]);
       // columns (:319-332)
       for (int c = 0; c < nvj; ++c) {
         double Sc[6], Jc[6], dJ[6], dVdq[6], dAdq[6], dAdv[6];
@@ -223,15 +222,15 @@ __global__ __launch_bounds__(WAVE) void rnea_deriv_kernel(const DerivArgs A) {
           for (int k = 0; k < 6; ++k) { dVdq[k] = 0.0; dAdv[k] = dJ[k]; }
         }
         const int col = 6 * (iv + c);
-        st6(wsl, J0 + DC_J * colsz + col, Jc);
-        st6(wsl, J0 + DC_DVDQ * colsz + col, dVdq);
-        st6(wsl, J0 + DC_DADQ * colsz + col, dAdq);
-        st6(wsl, J0 + DC_DADV * colsz + col, dAdv);
+        st6(W, J0 + DC_J * colsz + col, Jc);
+        st6(W, J0 + DC_DVDQ * colsz + col, dVdq);
+        st6(W, J0 + DC_DADQ * colsz + col, dAdq);
+        st6(W, J0 + DC_DADV * colsz + col, dAdv);
       }
       double dY[36];
       inertia_variation(jc.m, cw, Iw, ov, oh, dY);  // :335-337
 #pragma unroll
-      for (int k = 0; k < 36; ++k) wsst(wsl, rec + DJ_DY + k, dY[k]);
+      for (int k = 0; k < 36; ++k) W.st(rec + DJ_DY + k, dY[k]);
     }
 
     // ------------------------------------------------------------ backward sweep (:378-459)
@@ -243,22 +242,22 @@ __global__ __launch_bounds__(WAVE) void rnea_deriv_kernel(const DerivArgs A) {
       const int ivp = iv + nvj, nvsp = nvs - nvj;
       const int rec = JR0 + DJ_SIZE * i, prec = JR0 + DJ_SIZE * p;
       double of[6], Ym, Yc[3], YI[6], dY[36];
-      ld6(wsl, rec + DJ_OF, of);
-      Ym = wsld(wsl, rec + DJ_Y);
+      ld6(W, rec + DJ_OF, of);
+      Ym = W.ld(rec + DJ_Y);
 #pragma unroll
-      for (int k = 0; k < 3; ++k) Yc[k] = wsld(wsl, rec + DJ_Y + 1 + k);
+      for (int k = 0; k < 3; ++k) Yc[k] = W.ld(rec + DJ_Y + 1 + k);
 #pragma unroll
-      for (int k = 0; k < 6; ++k) YI[k] = wsld(wsl, rec + DJ_Y + 4 + k);
+      for (int k = 0; k < 6; ++k) YI[k] = W.ld(rec + DJ_Y + 4 + k);
 #pragma unroll
-      for (int k = 0; k < 36; ++k) dY[k] = wsld(wsl, rec + DJ_DY + k);
+      for (int k = 0; k < 36; ++k) dY[k] = W.ld(rec + DJ_DY + k);
       // per own column: the 6-vectors that only depend on this joint
       for (int c = 0; c < nvj; ++c) {
         const int col = 6 * (iv + c);
         double Jc[6], dVdq[6], dAdq[6], dAdv[6], dFda[6], dFdq[6], dFdv[6], dYtJ[6], tmp[6];
-        ld6(wsl, DC_J * colsz + col, Jc);
-        ld6(wsl, DC_DVDQ * colsz + col, dVdq);
-        ld6(wsl, DC_DADQ * colsz + col, dAdq);
-        ld6(wsl, DC_DADV * colsz + col, dAdv);
+        ld6(W, DC_J * colsz + col, Jc);
+        ld6(W, DC_DVDQ * colsz + col, dVdq);
+        ld6(W, DC_DADQ * colsz + col, dAdq);
+        ld6(W, DC_DADV * colsz + col, dAdv);
         if (wantTau) {  // :409-410 (+ armature, :538-539)
           const double x = dot6(Jc, of) + jc.arm[c] * ain.get(iv + c);
           if (valid) ptau.put(iv + c, x);
@@ -281,28 +280,28 @@ __global__ __launch_bounds__(WAVE) void rnea_deriv_kernel(const DerivArgs A) {
         inertia_mul(Ym, Yc, YI, dAdv, tmp);
 #pragma unroll
         for (int k = 0; k < 6; ++k) dFdv[k] += tmp[k];
-        st6(wsl, DC_DFDA * colsz + col, dFda);
-        st6(wsl, DC_DFDQ * colsz + col, dFdq);
-        st6(wsl, DC_DFDV * colsz + col, dFdv);
-        st6(wsl, DC_DYTJ * colsz + col, dYtJ);
+        st6(W, DC_DFDA * colsz + col, dFda);
+        st6(W, DC_DFDQ * colsz + col, dFdq);
+        st6(W, DC_DFDV * colsz + col, dFdv);
+        st6(W, DC_DYTJ * colsz + col, dYtJ);
       }
       // row blocks: rows = own dofs, columns = whole subtree (:420-421, :437-438, :450-451)
       for (int r = 0; r < nvj; ++r) {
         double Jr[6];
-        ld6(wsl, DC_J * colsz + 6 * (iv + r), Jr);
+        ld6(W, DC_J * colsz + 6 * (iv + r), Jr);
         for (int c = 0; c < nvs; ++c) {
           double x[6];
           const int col = 6 * (iv + c);
           const int e = (iv + c) * nv + iv + r;
           if (wantM) {
-            ld6(wsl, DC_DFDA * colsz + col, x);
+            ld6(W, DC_DFDA * colsz + col, x);
             double mval = dot6(Jr, x);
             if (c == r) mval += jc.arm[r];  // :540
             if (valid) pda.put(e, mval);
           }
-          ld6(wsl, DC_DFDQ * colsz + col, x);
+          ld6(W, DC_DFDQ * colsz + col, x);
           const double dqv = dot6(Jr, x);
-          ld6(wsl, DC_DFDV * colsz + col, x);
+          ld6(W, DC_DFDV * colsz + col, x);
           const double dvv = dot6(Jr, x);
           if (valid) { pdq.put(e, dqv); pdv.put(e, dvv); }
         }
@@ -311,14 +310,14 @@ __global__ __launch_bounds__(WAVE) void rnea_deriv_kernel(const DerivArgs A) {
       for (int c = 0; c < nvj; ++c) {
         double Jc[6], dVdq[6], dAdq[6], dAdv[6];
         const int col = 6 * (iv + c);
-        ld6(wsl, DC_J * colsz + col, Jc);
-        ld6(wsl, DC_DVDQ * colsz + col, dVdq);
-        ld6(wsl, DC_DADQ * colsz + col, dAdq);
-        ld6(wsl, DC_DADV * colsz + col, dAdv);
+        ld6(W, DC_J * colsz + col, Jc);
+        ld6(W, DC_DVDQ * colsz + col, dVdq);
+        ld6(W, DC_DADQ * colsz + col, dAdq);
+        ld6(W, DC_DADV * colsz + col, dAdv);
         for (int r = 0; r < nvsp; ++r) {
           double fa[6], yj[6];
-          ld6(wsl, DC_DFDA * colsz + 6 * (ivp + r), fa);
-          ld6(wsl, DC_DYTJ * colsz + 6 * (ivp + r), yj);
+          ld6(W, DC_DFDA * colsz + 6 * (ivp + r), fa);
+          ld6(W, DC_DYTJ * colsz + 6 * (ivp + r), yj);
           const int e = (iv + c) * nv + ivp + r;
           const double dqv = dot6(fa, dAdq) + dot6(yj, dVdq);
           const double dvv = dot6(fa, dAdv) + dot6(yj, Jc);
@@ -326,19 +325,19 @@ __global__ __launch_bounds__(WAVE) void rnea_deriv_kernel(const DerivArgs A) {
         }
         // :440 dFdq_cols += J_cols x* of   (after the dq row block used dFdq)
         double dFdq[6], tmp[6];
-        ld6(wsl, DC_DFDQ * colsz + col, dFdq);
+        ld6(W, DC_DFDQ * colsz + col, dFdq);
         force_cross(Jc, of, tmp);
 #pragma unroll
         for (int k = 0; k < 6; ++k) dFdq[k] += tmp[k];
-        st6(wsl, DC_DFDQ * colsz + col, dFdq);
+        st6(W, DC_DFDQ * colsz + col, dFdq);
       }
       if (p > 0) {  // :453-458
         // Ycrb[p] += Ycrb[i] (inertia.hpp:672-686)
-        double Pm = wsld(wsl, prec + DJ_Y), Pc[3], PI[6];
+        double Pm = W.ld(prec + DJ_Y), Pc[3], PI[6];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) Pc[k] = wsld(wsl, prec + DJ_Y + 1 + k);
+        for (int k = 0; k < 3; ++k) Pc[k] = W.ld(prec + DJ_Y + 1 + k);
 #pragma unroll
-        for (int k = 0; k < 6; ++k) PI[k] = wsld(wsl, prec + DJ_Y + 4 + k);
+        for (int k = 0; k < 6; ++k) PI[k] = W.ld(prec + DJ_Y + 4 + k);
         const double eps = 2.220446049250313e-16;
         const double mab = Pm + Ym;
         const double mab_inv = 1.0 / (mab > eps ? mab : eps);
@@ -356,15 +355,15 @@ __global__ __launch_bounds__(WAVE) void rnea_deriv_kernel(const DerivArgs A) {
         PI[3] = (PI[3] + YI[3]) - coef * (AB[0] * AB[2]);
         PI[4] = (PI[4] + YI[4]) - coef * (AB[1] * AB[2]);
         PI[5] = (PI[5] + YI[5]) - coef * (AB[2] * AB[2] - n2);
-        wsst(wsl, prec + DJ_Y, mab);
+        W.st(prec + DJ_Y, mab);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) wsst(wsl, prec + DJ_Y + 1 + k, Pc[k]);
+        for (int k = 0; k < 3; ++k) W.st(prec + DJ_Y + 1 + k, Pc[k]);
 #pragma unroll
-        for (int k = 0; k < 6; ++k) wsst(wsl, prec + DJ_Y + 4 + k, PI[k]);
+        for (int k = 0; k < 6; ++k) W.st(prec + DJ_Y + 4 + k, PI[k]);
 #pragma unroll
-        for (int k = 0; k < 36; ++k) wsst(wsl, prec + DJ_DY + k, wsld(wsl, prec + DJ_DY + k) + dY[k]);
+        for (int k = 0; k < 36; ++k) W.st(prec + DJ_DY + k, W.ld(prec + DJ_DY + k) + dY[k]);
 #pragma unroll
-        for (int k = 0; k < 6; ++k) wsst(wsl, prec + DJ_OF + k, wsld(wsl, prec + DJ_OF + k) + of[k]);
+        for (int k = 0; k < 6; ++k) W.st(prec + DJ_OF + k, W.ld(prec + DJ_OF + k) + of[k]);
       }
     }
   }

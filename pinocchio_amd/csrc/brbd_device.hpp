@@ -65,8 +65,12 @@ struct alignas(16) Op {
   int32_t joint;
   int32_t flags;
   int32_t depth;  // slot in the depth-indexed stack
-  int32_t bslot;  // FWD: branch slot to read the parent's state from (when !FROM_REGS);
-                  //      own branch slot to push to (when PUSH_BRANCH) is in bits 16.. of flags
+  int32_t bslot;  // branch slot of the PARENT (to read its state / reach its accumulator);
+                  // the joint's own branch slot is in bits 16.. of flags
+  // integer description of the joint, duplicated here so that a compile-time program carries
+  // everything the control flow depends on (the numeric constants stay in JointConst)
+  int32_t jtype, idx_q, idx_v, nvj;
+  int32_t comp, hand_off, pad0, pad1;
 };
 enum : int {
   OP_BWD = 1,          // backward visit of a non-leaf joint
@@ -84,6 +88,15 @@ DI Op load_op(const Op* prog, int s) {
   const Op BRBD_CONSTANT* p = as_constant(prog) + s;
   Op o;
   o.joint = p->joint; o.flags = p->flags; o.depth = p->depth; o.bslot = p->bslot;
+  o.jtype = p->jtype; o.idx_q = p->idx_q; o.idx_v = p->idx_v; o.nvj = p->nvj;
+  o.comp = p->comp; o.hand_off = p->hand_off; o.pad0 = 0; o.pad1 = 0;
+  return o;
+}
+DI Op op_from_joint(const JointConst& jc, int joint) {
+  Op o;
+  o.joint = joint; o.flags = 0; o.depth = 0; o.bslot = 0;
+  o.jtype = jc.jtype; o.idx_q = jc.idx_q; o.idx_v = jc.idx_v; o.nvj = jc.nvj;
+  o.comp = jc.comp; o.hand_off = jc.hand_off; o.pad0 = 0; o.pad1 = 0;
   return o;
 }
 

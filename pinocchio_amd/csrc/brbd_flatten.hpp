@@ -131,12 +131,18 @@ inline std::string flatten(const brbd_model_desc* d, FlatModel* out, int* status
   struct Frame { int joint; size_t next; };
   std::vector<Frame> stack;
   int last_fwd = -1;  // joint whose forward state is in registers
+  auto fill_ints = [&](Op& op, int i) {
+    const JointConst& jc = M.tab[i];
+    op.jtype = jc.jtype; op.idx_q = jc.idx_q; op.idx_v = jc.idx_v; op.nvj = jc.nvj;
+    op.comp = jc.comp; op.hand_off = jc.hand_off; op.pad0 = 0; op.pad1 = 0;
+  };
   auto emit_fwd = [&](int i) {
     const int p = d->parents[i];
     Op op;
     op.joint = i;
     op.depth = depth[i];
     op.bslot = p == 0 ? 0 : bslot[p];
+    fill_ints(op, i);
     int fl = 0;
     if (p == 0) fl |= F_PARENT_ROOT;
     else if (last_fwd == p) fl |= F_FROM_REGS;
@@ -157,6 +163,7 @@ inline std::string flatten(const brbd_model_desc* d, FlatModel* out, int* status
     op.joint = i;
     op.depth = depth[i];
     op.bslot = p == 0 ? 0 : bslot[p];
+    fill_ints(op, i);
     int fl = OP_BWD;
     if (p == 0) fl |= F_PARENT_ROOT;
     else if (children[p].size() == 1) fl |= F_CARRY_REGS;

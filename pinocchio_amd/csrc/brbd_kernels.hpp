@@ -1,13 +1,22 @@
-// brbd_kernels.hpp -- generic (table-driven) batch kernels: RNEA, ABA (WORLD), FK + Jacobians.
+// brbd_kernels.hpp -- batch kernels: RNEA, ABA (WORLD), FK + Jacobians.
 //
 // Execution model
 //   * one lane = one instance, one wave (64 lanes) = one workgroup, grid-stride over tiles of 64
-//     instances, so the per-wave spill workspace is bounded by the grid, not by the batch;
+//     instances, so any per-wave spill workspace is bounded by the grid, not by the batch;
 //   * the kinematic tree is walked by a depth-first PROGRAM built by the flattener
 //     (brbd_flatten.hpp): a joint's forward visit, its subtree, then its backward visit.  Only the
-//     joints on the current root path are live, chains hand state parent->child and
-//     child->parent in registers, and only branching joints spill to the workspace;
+//     joints on the current root path are live; chains hand state parent->child and
+//     child->parent in registers;
 //   * every control decision (op kind, joint kind, flags) is wave-uniform: no divergence.
+//
+// Each algorithm is ONE step function (`*_step`) instantiated twice:
+//   * generic kernels interpret the program at run time (any model; the live path state is kept
+//     in a wave-private, coalesced global workspace: GlobalStore);
+//   * static kernels (brbd_static.hpp) unroll a compile-time program for a registered topology:
+//     flags, joint kinds and stack slots fold to constants, the live path state becomes registers
+//     (RegStore) and the whole recursion is one straight-line instruction stream the compiler can
+//     schedule (loads hoisted far ahead of use), which is what hides HBM latency at one wave per
+//     SIMD (batch 65536 = exactly 1024 waves on 1024 SIMDs).
 //
 // Reference recursions: algorithm/rnea.hxx:45-161, algorithm/aba.hxx:102-294,
 // algorithm/kinematics.hxx:52-97, algorithm/jacobian.hxx:38-95.
@@ -21,7 +30,7 @@ constexpr int WAVE = 64;
 struct KArgs {
   const JointConst* tab;
   const Op* prog;   // pass 1+2 program (FWD/BWD ops)
-  const Op* prog3;  // ABA pass 3 program (FWD ops only)
+  const Op* prog3;  // forward-only program (ABA pass 3, FK/Jacobians)
   int32_t nops, nops3;
   int32_t njoints, nq, nv;
   int32_t maxdepth, maxbranch;
@@ -37,28 +46,70 @@ struct KArgs {
   double* out2; int64_t ldout2;  // FKJ: oMi
 };
 
-// Element (d, b) of a dof x B matrix in the two boundary layouts (include/brbd.h).
+// ---- boundary matrices -------------------------------------------------------------------------
+// Element (d, b) of a dof x B matrix in the two layouts of include/brbd.h.  Lanes past the end of
+// the batch are clamped onto the last instance: they recompute and re-store exactly its values,
+// which keeps every load/store unpredicated and the control flow uniform.
 template <int LAYOUT>
-struct Mat {
-  double* p;
+struct Mat;
+template <>
+struct Mat<1> {  // BATCH_MAJOR: uniform row base (SGPR pair) + 32-bit lane offset (saddr addressing)
+  double* p;     // base + tile * 64
   int64_t ld;
-  int64_t b;
-  DI double get(int d) const { return LAYOUT ? p[(int64_t)d * ld + b] : p[b * ld + d]; }
+  unsigned lo8;  // clamped lane, in bytes (zero-extended 32-bit offset -> saddr addressing)
+  DI Mat(double* base, int64_t ld_, int64_t tile, int64_t B, int lane) : p(base + tile * WAVE), ld(ld_) {
+    const int64_t left = B - tile * WAVE;  // >= 1
+    lo8 = ((int64_t)lane < left ? (unsigned)lane : (unsigned)(left - 1)) * 8u;
+  }
+  DI double get(int d) const {
+    return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(p + (int64_t)d * ld) + lo8);
+  }
   DI void put(int d, double x) const {
-    if (LAYOUT) p[(int64_t)d * ld + b] = x; else p[b * ld + d] = x;
+    *reinterpret_cast<double*>(reinterpret_cast<char*>(p + (int64_t)d * ld) + lo8) = x;
   }
 };
+template <>
+struct Mat<0> {  // INSTANCE_MAJOR: per-lane row pointer, uniform element index
+  double* row;
+  DI Mat(double* base, int64_t ld_, int64_t tile, int64_t B, int lane) {
+    int64_t b = tile * WAVE + lane;
+    if (b >= B) b = B - 1;
+    row = base + b * ld_;
+  }
+  DI double get(int d) const { return row[d]; }
+  DI void put(int d, double x) const { row[d] = x; }
+};
 
-// Wave-private workspace slot s of this lane: coalesced 512-byte rows.
-DI double wsld(const double* w, int slot) { return w[(int64_t)slot * WAVE]; }
-DI void wsst(double* w, int slot, double x) { w[(int64_t)slot * WAVE] = x; }
+// ---- live-state storage policies -----------------------------------------------------------------
+// GlobalStore: slot s of this lane lives at base[s * 64 + lane]: one coalesced 512-byte row per
+// slot, uniform base + lane offset.
+struct GlobalStore {
+  double* base;
+  unsigned lane8;  // lane * 8 bytes
+  DI GlobalStore(double* b, unsigned lane) : base(b), lane8(lane * 8u) {}
+  DI double ld(int slot) const {
+    return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base + (int64_t)slot * WAVE) + lane8);
+  }
+  DI void st(int slot, double x) const {
+    *reinterpret_cast<double*>(reinterpret_cast<char*>(base + (int64_t)slot * WAVE) + lane8) = x;
+  }
+};
+// RegStore: slots are elements of a local array; with a compile-time program every index is a
+// constant after inlining, SROA turns the array into registers and the register allocator keeps
+// exactly the live path in VGPRs (anything beyond 512 VGPRs falls back to scratch by itself).
+template <int N>
+struct RegStore {
+  double r[N > 0 ? N : 1];
+  DI double ld(int slot) const { return r[slot]; }
+  DI void st(int slot, double x) { r[slot] = x; }
+};
 
-// ---- joint kinematics: liMi = placement * M(q) -------------------------------------------------
+// ---- joint kinematics: liMi = placement * M(q) ---------------------------------------------------
 // have_sc: (s, c) already known (backward visit / pass 3), skip sincos.
-template <int LAYOUT>
-DI void joint_liMi(const JointConst& jc, const Mat<LAYOUT>& q, bool have_sc, double& s, double& c,
+template <class MatT>
+DI void joint_liMi(const JointConst& jc, const Op& op, const MatT& q, bool have_sc, double& s, double& c,
                    double* R, double* t) {
-  const int jt = jc.jtype, iq = jc.idx_q;
+  const int jt = op.jtype, iq = op.idx_q;
   switch (jt) {
     case JT_RX: case JT_RY: case JT_RZ: case JT_RUBX: case JT_RUBY: case JT_RUBZ: {
       if (!have_sc) {
@@ -110,15 +161,15 @@ DI void joint_liMi(const JointConst& jc, const Mat<LAYOUT>& q, bool have_sc, dou
 }
 
 // Dense S * x for the joint (x = joint velocity or acceleration read from `m`)
-template <int LAYOUT>
-DI void joint_S_times(const JointConst& jc, const Mat<LAYOUT>& m, double* o) {
-  const int iv = jc.idx_v;
-  if (jc.nvj == 1) {
+template <class MatT>
+DI void joint_S_times(const Op& op, const MatT& m, double* o) {
+  const int iv = op.idx_v;
+  if (op.nvj == 1) {
     const double x = m.get(iv);
-    const int comp = jc.comp;
+    const int comp = op.comp;
 #pragma unroll
     for (int k = 0; k < 6; ++k) o[k] = (k == comp) ? x : 0.0;
-  } else if (jc.nvj == 6) {
+  } else if (op.nvj == 6) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) o[k] = m.get(iv + k);
   } else {
@@ -128,138 +179,136 @@ DI void joint_S_times(const JointConst& jc, const Mat<LAYOUT>& m, double* o) {
 }
 
 // =================================================================================== RNEA
-// workspace slots per lane: F[depth][8] = f(6) + (s, c);  VA[bslot][12] = v(6) + a_gf(6)
+// live-state slots per lane: F[depth][8] = f(6) + (s, c);  VA[bslot][12] = v(6) + a_gf(6)
+struct RneaState {
+  double v[6], a[6], carry[6];
+};
+DI void rnea_state_init(RneaState& st) {
+#pragma unroll
+  for (int k = 0; k < 6; ++k) st.v[k] = st.a[k] = st.carry[k] = 0.0;
+}
+
+template <class MatT, class Stack>
+DI void rnea_step(const KArgs& A, const Op op, Stack& S, const int VA0, const MatT& q, const MatT& vin,
+                  const MatT& ain, const MatT& tau, RneaState& st) {
+  JointConst jc;
+  load_joint(A.tab, op.joint, jc);
+  const int fl = op.flags;
+  double R[9], t[3], f[6], sn = 0.0, cs = 1.0;
+  if (!(fl & OP_BWD)) {
+    // ---------------- forward visit (rnea.hxx:45-79) ----------------
+    double vp[6], ap[6];
+    if (fl & F_PARENT_ROOT) {  // rnea.hxx:137-138: v[0] = 0, a_gf[0] = -gravity
+#pragma unroll
+      for (int k = 0; k < 6; ++k) vp[k] = ap[k] = 0.0;
+      ap[0] = -A.gx; ap[1] = -A.gy; ap[2] = -A.gz;
+    } else if (fl & F_FROM_REGS) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { vp[k] = st.v[k]; ap[k] = st.a[k]; }
+    } else {
+      const int base = VA0 + op.bslot * 12;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { vp[k] = S.ld(base + k); ap[k] = S.ld(base + 6 + k); }
+    }
+    joint_liMi(jc, op, q, false, sn, cs, R, t);
+    double vJ[6], Sa[6], tmp[6];
+    joint_S_times(op, vin, vJ);
+    joint_S_times(op, ain, Sa);
+    if (fl & F_PARENT_ROOT) {  // :63-65, velocity propagation guarded by parent > 0
+#pragma unroll
+      for (int k = 0; k < 6; ++k) st.v[k] = vJ[k];
+    } else {
+      se3_actinv_motion(R, t, vp, tmp);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) st.v[k] = vJ[k] + tmp[k];
+    }
+    motion_cross(st.v, vJ, st.a);      // :67 (c = 0)
+    se3_actinv_motion(R, t, ap, tmp);  // :69 (not guarded)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) st.a[k] = (st.a[k] + Sa[k]) + tmp[k];
+    double h[6];
+    inertia_mul(jc.m, jc.c, jc.I, st.v, h);  // :73
+    inertia_mul(jc.m, jc.c, jc.I, st.a, f);  // :74
+    force_cross(st.v, h, tmp);               // :75
+#pragma unroll
+    for (int k = 0; k < 6; ++k) f[k] += tmp[k];
+    if (fl & F_PUSH_BRANCH) {
+      const int base = VA0 + op_own_bslot(fl) * 12;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { S.st(base + k, st.v[k]); S.st(base + 6 + k, st.a[k]); }
+    }
+    if (!(fl & F_LEAF)) {
+      const int base = op.depth * 8;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) S.st(base + k, f[k]);
+      S.st(base + 6, sn);
+      S.st(base + 7, cs);
+      return;
+    }
+  } else {
+    // ---------------- backward visit of a non-leaf joint (rnea.hxx:92-107) ----------------
+    const int base = op.depth * 8;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) f[k] = S.ld(base + k);
+    sn = S.ld(base + 6);
+    cs = S.ld(base + 7);
+    if (fl & F_CARRY_IN) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) f[k] += st.carry[k];
+    }
+    joint_liMi(jc, op, q, true, sn, cs, R, t);
+  }
+  // ---- common tail: tau = S^T f (+ armature * a), hand f to the parent ----
+  const int iv = op.idx_v;
+  if (op.nvj == 1) {
+    const int comp = op.comp;
+    double x = f[0];
+#pragma unroll
+    for (int k = 1; k < 6; ++k) x = (k == comp) ? f[k] : x;
+    x += jc.arm[0] * ain.get(iv);  // rnea.hxx:158
+    tau.put(iv, x);
+  } else if (op.nvj == 6) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) tau.put(iv + k, f[k] + jc.arm[k] * ain.get(iv + k));
+  } else {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) tau.put(iv + k, f[3 + k] + jc.arm[k] * ain.get(iv + k));
+  }
+  if (!(fl & F_PARENT_ROOT)) {  // :105-106
+    double up[6];
+    se3_act_force(R, t, f, up);
+    if (fl & F_CARRY_REGS) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) st.carry[k] = up[k];
+    } else {
+      const int pbase = (op.depth - 1) * 8;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) S.st(pbase + k, S.ld(pbase + k) + up[k]);
+    }
+  }
+}
+
 template <int LAYOUT>
 __global__ __launch_bounds__(WAVE) void rnea_kernel(const KArgs A) {
   const int lane = threadIdx.x;
-  double* const wsl = A.ws + (int64_t)blockIdx.x * A.ws_stride + lane;
+  GlobalStore S(A.ws + (int64_t)blockIdx.x * A.ws_stride, (unsigned)lane);
   const int VA0 = A.maxdepth * 8;
   for (int64_t tile = blockIdx.x; tile < A.ntiles; tile += gridDim.x) {
-    const int64_t b0 = tile * WAVE + lane;
-    const bool valid = b0 < A.B;
-    const int64_t b = valid ? b0 : A.B - 1;
-    const Mat<LAYOUT> q{const_cast<double*>(A.q), A.ldq, b};
-    const Mat<LAYOUT> vin{const_cast<double*>(A.v), A.ldv, b};
-    const Mat<LAYOUT> ain{const_cast<double*>(A.a), A.lda, b};
-    const Mat<LAYOUT> tau{A.out, A.ldout, b};
-    double v[6], a[6], carry[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) v[k] = a[k] = carry[k] = 0.0;
-
-    for (int s = 0; s < A.nops; ++s) {
-      const Op op = load_op(A.prog, s);
-      JointConst jc;
-      load_joint(A.tab, op.joint, jc);
-      const int fl = op.flags;
-      double R[9], t[3], f[6], sn = 0.0, cs = 1.0;
-      if (!(fl & OP_BWD)) {
-        // ---------------- forward visit (rnea.hxx:45-79) ----------------
-        double vp[6], ap[6];
-        if (fl & F_PARENT_ROOT) {  // rnea.hxx:137-138: v[0] = 0, a_gf[0] = -gravity
-#pragma unroll
-          for (int k = 0; k < 6; ++k) vp[k] = ap[k] = 0.0;
-          ap[0] = -A.gx; ap[1] = -A.gy; ap[2] = -A.gz;
-        } else if (fl & F_FROM_REGS) {
-#pragma unroll
-          for (int k = 0; k < 6; ++k) { vp[k] = v[k]; ap[k] = a[k]; }
-        } else {
-          const int base = VA0 + op.bslot * 12;
-#pragma unroll
-          for (int k = 0; k < 6; ++k) { vp[k] = wsld(wsl, base + k); ap[k] = wsld(wsl, base + 6 + k); }
-        }
-        joint_liMi<LAYOUT>(jc, q, false, sn, cs, R, t);
-        double vJ[6], Sa[6], tmp[6];
-        joint_S_times<LAYOUT>(jc, vin, vJ);
-        joint_S_times<LAYOUT>(jc, ain, Sa);
-        if (fl & F_PARENT_ROOT) {  // :63-65, velocity propagation guarded by parent > 0
-#pragma unroll
-          for (int k = 0; k < 6; ++k) v[k] = vJ[k];
-        } else {
-          se3_actinv_motion(R, t, vp, tmp);
-#pragma unroll
-          for (int k = 0; k < 6; ++k) v[k] = vJ[k] + tmp[k];
-        }
-        motion_cross(v, vJ, a);             // :67 (c = 0)
-        se3_actinv_motion(R, t, ap, tmp);   // :69 (not guarded)
-#pragma unroll
-        for (int k = 0; k < 6; ++k) a[k] = (a[k] + Sa[k]) + tmp[k];
-        double h[6];
-        inertia_mul(jc.m, jc.c, jc.I, v, h);  // :73
-        inertia_mul(jc.m, jc.c, jc.I, a, f);  // :74
-        force_cross(v, h, tmp);               // :75
-#pragma unroll
-        for (int k = 0; k < 6; ++k) f[k] += tmp[k];
-        if (fl & F_PUSH_BRANCH) {
-          const int base = VA0 + op_own_bslot(fl) * 12;
-#pragma unroll
-          for (int k = 0; k < 6; ++k) { wsst(wsl, base + k, v[k]); wsst(wsl, base + 6 + k, a[k]); }
-        }
-        if (!(fl & F_LEAF)) {
-          const int base = op.depth * 8;
-#pragma unroll
-          for (int k = 0; k < 6; ++k) wsst(wsl, base + k, f[k]);
-          wsst(wsl, base + 6, sn);
-          wsst(wsl, base + 7, cs);
-          continue;
-        }
-      } else {
-        // ---------------- backward visit of a non-leaf joint (rnea.hxx:92-107) ----------------
-        const int base = op.depth * 8;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) f[k] = wsld(wsl, base + k);
-        sn = wsld(wsl, base + 6);
-        cs = wsld(wsl, base + 7);
-        if (fl & F_CARRY_IN) {
-#pragma unroll
-          for (int k = 0; k < 6; ++k) f[k] += carry[k];
-        }
-        joint_liMi<LAYOUT>(jc, q, true, sn, cs, R, t);
-      }
-      // ---- common tail: tau = S^T f (+ armature * a), hand f to the parent ----
-      {
-        const int iv = jc.idx_v;
-        if (jc.nvj == 1) {
-          const int comp = jc.comp;
-          double x = f[0];
-#pragma unroll
-          for (int k = 1; k < 6; ++k) x = (k == comp) ? f[k] : x;
-          x += jc.arm[0] * ain.get(iv);  // rnea.hxx:158
-          if (valid) tau.put(iv, x);
-        } else if (jc.nvj == 6) {
-#pragma unroll
-          for (int k = 0; k < 6; ++k) {
-            const double x = f[k] + jc.arm[k] * ain.get(iv + k);
-            if (valid) tau.put(iv + k, x);
-          }
-        } else {
-#pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            const double x = f[3 + k] + jc.arm[k] * ain.get(iv + k);
-            if (valid) tau.put(iv + k, x);
-          }
-        }
-        if (!(fl & F_PARENT_ROOT)) {  // :105-106
-          double up[6];
-          se3_act_force(R, t, f, up);
-          if (fl & F_CARRY_REGS) {
-#pragma unroll
-            for (int k = 0; k < 6; ++k) carry[k] = up[k];
-          } else {
-            const int pbase = (op.depth - 1) * 8;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) wsst(wsl, pbase + k, wsld(wsl, pbase + k) + up[k]);
-          }
-        }
-      }
-    }
+    const Mat<LAYOUT> q(const_cast<double*>(A.q), A.ldq, tile, A.B, lane);
+    const Mat<LAYOUT> vin(const_cast<double*>(A.v), A.ldv, tile, A.B, lane);
+    const Mat<LAYOUT> ain(const_cast<double*>(A.a), A.lda, tile, A.B, lane);
+    const Mat<LAYOUT> tau(A.out, A.ldout, tile, A.B, lane);
+    RneaState st;
+    rnea_state_init(st);
+    for (int s = 0; s < A.nops; ++s) rnea_step(A, load_op(A.prog, s), S, VA0, q, vin, ain, tau, st);
   }
 }
 
 // =================================================================================== ABA (WORLD)
 // J columns of a joint in the world frame: oMi.act(S) (aba.hxx:124, jacobian.hxx:59)
 // 1-dof aligned: revolute k -> [t x R[:,k]; R[:,k]], prismatic k -> [R[:,k]; 0]
-DI void jcol_1dof(const JointConst& jc, const double* R, const double* t, double* J) {
-  const int comp = jc.comp;
+DI void jcol_1dof(const Op& op, const double* R, const double* t, double* J) {
+  const int comp = op.comp;
   const int k = comp >= 3 ? comp - 3 : comp;
   double col[3];
 #pragma unroll
@@ -294,12 +343,12 @@ DI void jcols_multi(const double* R, const double* t, double* J /* NV x 6 */) {
 
 // world kinematics of one joint from its parent's (oMp, ovp): oMi, ov, bias = ovp x ov
 // (aba.hxx:115-132).  root: parent == 0.
-template <int LAYOUT>
-DI void aba_kin(const JointConst& jc, const Mat<LAYOUT>& q, const Mat<LAYOUT>& vin, bool root,
+template <class MatT>
+DI void aba_kin(const JointConst& jc, const Op& op, const MatT& q, const MatT& vin, bool root,
                 bool have_sc, double& sn, double& cs, const double* Rp, const double* tp,
                 const double* ovp, double* R, double* t, double* ov, double* bias) {
   double Rl[9], tl[3];
-  joint_liMi<LAYOUT>(jc, q, have_sc, sn, cs, Rl, tl);
+  joint_liMi(jc, op, q, have_sc, sn, cs, Rl, tl);
   if (root) {
 #pragma unroll
     for (int i = 0; i < 9; ++i) R[i] = Rl[i];
@@ -311,7 +360,7 @@ DI void aba_kin(const JointConst& jc, const Mat<LAYOUT>& q, const Mat<LAYOUT>& v
     t[0] = tp[0] + Rt[0]; t[1] = tp[1] + Rt[1]; t[2] = tp[2] + Rt[2];
   }
   double vJ[6], ovJ[6];
-  joint_S_times<LAYOUT>(jc, vin, vJ);
+  joint_S_times(op, vin, vJ);
   se3_act_motion(R, t, vJ, ovJ);  // aba.hxx:126
   if (root) {
 #pragma unroll
@@ -333,34 +382,39 @@ DI void aba_own_inertia(const JointConst& jc, const double* R, const double* t, 
   force_cross(ov, h, of);
 }
 
-// workspace slots per lane (ABA):
+// live-state slots per lane (ABA), "stack" part:
 //   KIN[depth][18]   = oMi (R 9, t 3) + ov (6)        (non-leaf joints, forward -> backward visit)
 //   ACC[bslot][27]   = Ia (21) + of (6)               (branching joints: own + children)
 //   KB[bslot][18]    = oMi + ov of a branching joint  (for its 2nd.. children, pass 1)
-//   HAND[...]        = per joint pass 2 -> pass 3 record (hand_off from the flattener)
 //   K3[bslot][24]    = oMi + ov + a of a branching joint (pass 3)
+// and, always in the global workspace (it lives from pass 2 to pass 3 for every joint):
+//   HAND[...]        = per joint hand-off record (hand_off from the flattener)
 struct AbaLayout {
-  int kin0, acc0, kb0, hand0, k30;
+  int kin0, acc0, kb0, k30, end;
 };
-DI AbaLayout aba_layout(const KArgs& A, int nhand) {
-  AbaLayout L;
+__host__ __device__ constexpr AbaLayout aba_layout(int maxdepth, int maxbranch) {
+  AbaLayout L{};
   L.kin0 = 0;
-  L.acc0 = L.kin0 + A.maxdepth * 18;
-  L.kb0 = L.acc0 + A.maxbranch * 27;
-  L.k30 = L.kb0 + A.maxbranch * 18;
-  L.hand0 = L.k30 + A.maxbranch * 24;
-  (void)nhand;
+  L.acc0 = L.kin0 + maxdepth * 18;
+  L.kb0 = L.acc0 + maxbranch * 27;
+  L.k30 = L.kb0 + maxbranch * 18;
+  L.end = L.k30 + maxbranch * 24;
   return L;
+}
+
+// hand-off record sizes (doubles) by joint dof count; +2 for the cached (s, c) at the end
+__host__ __device__ constexpr int hand_size(int nvj) {
+  return (nvj == 1 ? 7 : 6 * nvj + nvj * nvj + nvj) + 2;
 }
 
 // Backward visit arithmetic for an NV-dof joint (aba.hxx:153-193).  Ia/of hold the accumulated
 // articulated inertia / bias force of the joint on entry and the contribution for the parent on
 // exit.  Writes the pass-3 hand-off record, or ddq directly for joints attached to the universe.
-template <int NV, int LAYOUT>
-DI void aba_backward(const KArgs& A, const JointConst& jc, double* wsl, int hand0, bool root,
-                     bool valid, const double* J, const double* bias, const Mat<LAYOUT>& tauin,
-                     const Mat<LAYOUT>& ddq, double* Ia, double* of) {
-  const int iv = jc.idx_v;
+template <int NV, class MatT>
+DI void aba_backward(const KArgs& A, const JointConst& jc, const Op& op, const GlobalStore& H, bool root,
+                     const double* J, const double* bias, const MatT& tauin, const MatT& ddq, double* Ia,
+                     double* of) {
+  const int iv = op.idx_v;
   double u[NV], U[NV * 6], D[NV * NV], Dinv[NV * NV], UD[NV * 6];
 #pragma unroll
   for (int c = 0; c < NV; ++c) u[c] = tauin.get(iv + c) - dot6(J + 6 * c, of);  // :173 (u = tau)
@@ -396,21 +450,21 @@ DI void aba_backward(const KArgs& A, const JointConst& jc, double* wsl, int hand
 #pragma unroll
       for (int c = 0; c < NV; ++c) s += Dinv[NV * r + c] * u[c];
       s -= dot6(UD + 6 * r, a0);
-      if (valid) ddq.put(iv + r, s);
+      ddq.put(iv + r, s);
     }
     return;
   }
   // hand-off record for pass 3: UDinv (6 NV), then NV==1: Dinv*u ; NV>1: Dinv (NV*NV), u (NV)
-  const int h = hand0 + jc.hand_off;
+  const int h = op.hand_off;
 #pragma unroll
-  for (int k = 0; k < 6 * NV; ++k) wsst(wsl, h + k, UD[k]);
+  for (int k = 0; k < 6 * NV; ++k) H.st(h + k, UD[k]);
   if (NV == 1) {
-    wsst(wsl, h + 6, Dinv[0] * u[0]);
+    H.st(h + 6, Dinv[0] * u[0]);
   } else {
 #pragma unroll
-    for (int k = 0; k < NV * NV; ++k) wsst(wsl, h + 6 * NV + k, Dinv[k]);
+    for (int k = 0; k < NV * NV; ++k) H.st(h + 6 * NV + k, Dinv[k]);
 #pragma unroll
-    for (int k = 0; k < NV; ++k) wsst(wsl, h + 6 * NV + NV * NV + k, u[k]);
+    for (int k = 0; k < NV; ++k) H.st(h + 6 * NV + NV * NV + k, u[k]);
   }
   // :186 Ia -= UDinv U^T
 #pragma unroll
@@ -434,398 +488,408 @@ DI void aba_backward(const KArgs& A, const JointConst& jc, double* wsl, int hand
   }
 }
 
-// hand-off record sizes (doubles) by joint dof count; +2 for the cached (s, c) at the end
-__host__ __device__ constexpr int hand_size(int nvj) {
-  return (nvj == 1 ? 7 : 6 * nvj + nvj * nvj + nvj) + 2;
+template <class MatT>
+DI void aba_backward_any(const KArgs& A, const JointConst& jc, const Op& op, const GlobalStore& H, bool root,
+                         const double* R, const double* t, const double* bias, const MatT& tauin,
+                         const MatT& ddq, double* Ia, double* of) {
+  if (op.nvj == 1) {
+    double J[6];
+    jcol_1dof(op, R, t, J);
+    aba_backward<1>(A, jc, op, H, root, J, bias, tauin, ddq, Ia, of);
+  } else if (op.nvj == 6) {
+    double J[36];
+    jcols_multi<6>(R, t, J);
+    aba_backward<6>(A, jc, op, H, root, J, bias, tauin, ddq, Ia, of);
+  } else {
+    double J[18];
+    jcols_multi<3>(R, t, J);
+    aba_backward<3>(A, jc, op, H, root, J, bias, tauin, ddq, Ia, of);
+  }
+}
+
+struct AbaState {
+  double R[9], t[3], ov[6];  // state of the most recent forward visit
+  double cIa[21], cof[6];    // carry registers child -> parent
+};
+DI void aba_state_init(AbaState& st) {
+#pragma unroll
+  for (int k = 0; k < 9; ++k) st.R[k] = 0.0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) st.t[k] = 0.0;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) st.ov[k] = st.cof[k] = 0.0;
+#pragma unroll
+  for (int k = 0; k < 21; ++k) st.cIa[k] = 0.0;
+}
+
+// one op of passes 1 + 2 (depth-first)
+template <class MatT, class Stack>
+DI void aba_step12(const KArgs& A, const Op op, const AbaLayout L, Stack& S, const GlobalStore& H,
+                   const MatT& q, const MatT& vin, const MatT& tauin, const MatT& ddq, AbaState& st) {
+  JointConst jc;
+  load_joint(A.tab, op.joint, jc);
+  const int fl = op.flags;
+  const bool root = fl & F_PARENT_ROOT;
+  double Ia[21], of[6], bias[6];
+  double sn = 0.0, cs = 1.0;
+  if (!(fl & OP_BWD)) {
+    // ---------------- forward visit (aba.hxx:102-139) ----------------
+    double Rp[9], tp[3], ovp[6];
+    if (fl & F_FROM_REGS) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) Rp[k] = st.R[k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) tp[k] = st.t[k];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) ovp[k] = st.ov[k];
+    } else if (!root) {
+      const int base = L.kb0 + op.bslot * 18;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) Rp[k] = S.ld(base + k);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) tp[k] = S.ld(base + 9 + k);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) ovp[k] = S.ld(base + 12 + k);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) Rp[k] = 0.0;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) tp[k] = 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) ovp[k] = 0.0;
+    }
+    aba_kin(jc, op, q, vin, root, false, sn, cs, Rp, tp, ovp, st.R, st.t, st.ov, bias);
+    // (s, c) of revolute joints go to the hand-off record for pass 3
+    {
+      const int h = op.hand_off + hand_size(op.nvj) - 2;
+      H.st(h, sn);
+      H.st(h + 1, cs);
+    }
+    if (fl & F_PUSH_BRANCH) {
+      const int bs = op_own_bslot(fl);
+      const int kb = L.kb0 + bs * 18;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) S.st(kb + k, st.R[k]);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) S.st(kb + 9 + k, st.t[k]);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) S.st(kb + 12 + k, st.ov[k]);
+      // accumulator starts with the joint's own inertia and bias force (aba.hxx:134-138)
+      aba_own_inertia(jc, st.R, st.t, st.ov, Ia, of);
+      const int ac = L.acc0 + bs * 27;
+#pragma unroll
+      for (int k = 0; k < 21; ++k) S.st(ac + k, Ia[k]);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) S.st(ac + 21 + k, of[k]);
+    }
+    if (!(fl & F_LEAF)) {
+      const int base = L.kin0 + op.depth * 18;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) S.st(base + k, st.R[k]);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) S.st(base + 9 + k, st.t[k]);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) S.st(base + 12 + k, st.ov[k]);
+      return;
+    }
+    // leaf: backward arithmetic right away with (R, t, ov, bias) in registers
+    aba_own_inertia(jc, st.R, st.t, st.ov, Ia, of);
+    aba_backward_any(A, jc, op, H, root, st.R, st.t, bias, tauin, ddq, Ia, of);
+  } else {
+    // ---------------- backward visit of a non-leaf joint (aba.hxx:153-193) ----------------
+    double Rb[9], tb[3], ovb[6];
+    const int base = L.kin0 + op.depth * 18;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Rb[k] = S.ld(base + k);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) tb[k] = S.ld(base + 9 + k);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) ovb[k] = S.ld(base + 12 + k);
+    double vJ[6], ovJ[6];
+    // bias = ov_parent x ov with ov_parent = ov - oMi.act(vJ) (aba.hxx:126-132)
+    joint_S_times(op, vin, vJ);
+    se3_act_motion(Rb, tb, vJ, ovJ);
+    if (root) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) bias[k] = 0.0;
+    } else {
+      double ovp[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) ovp[k] = ovb[k] - ovJ[k];
+      motion_cross(ovp, ovb, bias);
+    }
+    if (fl & F_MULTI) {
+      const int ac = L.acc0 + op_own_bslot(fl) * 27;
+#pragma unroll
+      for (int k = 0; k < 21; ++k) Ia[k] = S.ld(ac + k);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) of[k] = S.ld(ac + 21 + k);
+    } else {
+      aba_own_inertia(jc, Rb, tb, ovb, Ia, of);
+#pragma unroll
+      for (int k = 0; k < 21; ++k) Ia[k] += st.cIa[k];  // aba.hxx:190-191 (single child)
+#pragma unroll
+      for (int k = 0; k < 6; ++k) of[k] += st.cof[k];
+    }
+    aba_backward_any(A, jc, op, H, root, Rb, tb, bias, tauin, ddq, Ia, of);
+  }
+  // ---- hand the articulated contribution to the parent (aba.hxx:190-191) ----
+  if (!root) {
+    if (fl & F_CARRY_REGS) {
+#pragma unroll
+      for (int k = 0; k < 21; ++k) st.cIa[k] = Ia[k];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) st.cof[k] = of[k];
+    } else {
+      const int ac = L.acc0 + op.bslot * 27;  // parent's accumulator
+#pragma unroll
+      for (int k = 0; k < 21; ++k) S.st(ac + k, S.ld(ac + k) + Ia[k]);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) S.st(ac + 21 + k, S.ld(ac + 21 + k) + of[k]);
+    }
+  }
+}
+
+struct Aba3State {
+  double R[9], t[3], ov[6], acc[6];
+};
+DI void aba3_state_init(Aba3State& st) {
+#pragma unroll
+  for (int k = 0; k < 9; ++k) st.R[k] = 0.0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) st.t[k] = 0.0;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) st.ov[k] = st.acc[k] = 0.0;
+}
+
+// one op of pass 3 (aba.hxx:207-232), forward
+template <class MatT, class Stack>
+DI void aba_step3(const KArgs& A, const Op op, const AbaLayout L, Stack& S, const GlobalStore& H,
+                  const MatT& q, const MatT& vin, const MatT& ddq, Aba3State& st) {
+  JointConst jc;
+  load_joint(A.tab, op.joint, jc);
+  const int fl = op.flags;
+  const bool root = fl & F_PARENT_ROOT;
+  double Rp[9], tp[3], ovp[6], ap[6];
+  if (root) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Rp[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) tp[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) ovp[k] = ap[k] = 0.0;
+    ap[0] = -A.gx; ap[1] = -A.gy; ap[2] = -A.gz;  // aba.hxx:261
+  } else if (fl & F_FROM_REGS) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Rp[k] = st.R[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) tp[k] = st.t[k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { ovp[k] = st.ov[k]; ap[k] = st.acc[k]; }
+  } else {
+    const int base = L.k30 + op.bslot * 24;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Rp[k] = S.ld(base + k);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) tp[k] = S.ld(base + 9 + k);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { ovp[k] = S.ld(base + 12 + k); ap[k] = S.ld(base + 18 + k); }
+  }
+  const int h = op.hand_off;
+  double sn = H.ld(h + hand_size(op.nvj) - 2);
+  double cs = H.ld(h + hand_size(op.nvj) - 1);
+  double bias[6];
+  aba_kin(jc, op, q, vin, root, true, sn, cs, Rp, tp, ovp, st.R, st.t, st.ov, bias);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) st.acc[k] = ap[k] + bias[k];  // :223 (oa_gf[i] += oa_gf[parent])
+  const int iv = op.idx_v;
+  const bool leaf = fl & F_LEAF;
+  if (op.nvj == 1) {
+    double dd;
+    if (root) {
+      dd = ddq.get(iv);  // written by the backward visit of this lane
+    } else {
+      double UD[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) UD[k] = H.ld(h + k);
+      dd = H.ld(h + 6) - dot6(UD, st.acc);  // :224-226
+      ddq.put(iv, dd);
+    }
+    if (!leaf) {
+      double J[6];
+      jcol_1dof(op, st.R, st.t, J);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) st.acc[k] += J[k] * dd;  // :227
+    }
+  } else if (op.nvj == 6) {
+    double dd[6], J[36];
+    if (root) {
+#pragma unroll
+      for (int r = 0; r < 6; ++r) dd[r] = ddq.get(iv + r);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        double sum = 0.0;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) sum += H.ld(h + 36 + 6 * r + c) * H.ld(h + 72 + c);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) sum -= H.ld(h + 6 * r + k) * st.acc[k];
+        dd[r] = sum;
+        ddq.put(iv + r, sum);
+      }
+    }
+    jcols_multi<6>(st.R, st.t, J);
+#pragma unroll
+    for (int c = 0; c < 6; ++c)
+#pragma unroll
+      for (int k = 0; k < 6; ++k) st.acc[k] += J[6 * c + k] * dd[c];
+  } else {
+    double dd[3], J[18];
+    if (root) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r) dd[r] = ddq.get(iv + r);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        double sum = 0.0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) sum += H.ld(h + 18 + 3 * r + c) * H.ld(h + 27 + c);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) sum -= H.ld(h + 6 * r + k) * st.acc[k];
+        dd[r] = sum;
+        ddq.put(iv + r, sum);
+      }
+    }
+    jcols_multi<3>(st.R, st.t, J);
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int k = 0; k < 6; ++k) st.acc[k] += J[6 * c + k] * dd[c];
+  }
+  if (fl & F_PUSH_BRANCH) {
+    const int base = L.k30 + op_own_bslot(fl) * 24;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) S.st(base + k, st.R[k]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) S.st(base + 9 + k, st.t[k]);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { S.st(base + 12 + k, st.ov[k]); S.st(base + 18 + k, st.acc[k]); }
+  }
 }
 
 template <int LAYOUT>
 __global__ __launch_bounds__(WAVE) void aba_kernel(const KArgs A) {
   const int lane = threadIdx.x;
-  double* const wsl = A.ws + (int64_t)blockIdx.x * A.ws_stride + lane;
-  const AbaLayout L = aba_layout(A, 0);
+  double* const wbase = A.ws + (int64_t)blockIdx.x * A.ws_stride;
+  const AbaLayout L = aba_layout(A.maxdepth, A.maxbranch);
+  GlobalStore S(wbase, (unsigned)lane);
+  const GlobalStore H(wbase + (int64_t)L.end * WAVE, (unsigned)lane);
   for (int64_t tile = blockIdx.x; tile < A.ntiles; tile += gridDim.x) {
-    const int64_t b0 = tile * WAVE + lane;
-    const bool valid = b0 < A.B;
-    const int64_t b = valid ? b0 : A.B - 1;
-    const Mat<LAYOUT> q{const_cast<double*>(A.q), A.ldq, b};
-    const Mat<LAYOUT> vin{const_cast<double*>(A.v), A.ldv, b};
-    const Mat<LAYOUT> tauin{const_cast<double*>(A.a), A.lda, b};
-    const Mat<LAYOUT> ddq{A.out, A.ldout, b};
-
-    // ------------------------------------------------ passes 1 + 2, depth-first
-    {
-      double R[9], t[3], ov[6];       // state of the most recent forward visit
-      double cIa[21], cof[6];         // carry registers child -> parent
-#pragma unroll
-      for (int k = 0; k < 9; ++k) R[k] = 0.0;
-#pragma unroll
-      for (int k = 0; k < 3; ++k) t[k] = 0.0;
-#pragma unroll
-      for (int k = 0; k < 6; ++k) ov[k] = cof[k] = 0.0;
-#pragma unroll
-      for (int k = 0; k < 21; ++k) cIa[k] = 0.0;
-
-      for (int s = 0; s < A.nops; ++s) {
-        const Op op = load_op(A.prog, s);
-        JointConst jc;
-      load_joint(A.tab, op.joint, jc);
-        const int fl = op.flags;
-        const bool root = fl & F_PARENT_ROOT;
-        double Ia[21], of[6], bias[6];
-        double sn = 0.0, cs = 1.0;
-        if (!(fl & OP_BWD)) {
-          // ---------------- forward visit (aba.hxx:102-139) ----------------
-          double Rp[9], tp[3], ovp[6];
-          if (fl & F_FROM_REGS) {
-#pragma unroll
-            for (int k = 0; k < 9; ++k) Rp[k] = R[k];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) tp[k] = t[k];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) ovp[k] = ov[k];
-          } else if (!root) {
-            const int base = L.kb0 + op.bslot * 18;
-#pragma unroll
-            for (int k = 0; k < 9; ++k) Rp[k] = wsld(wsl, base + k);
-#pragma unroll
-            for (int k = 0; k < 3; ++k) tp[k] = wsld(wsl, base + 9 + k);
-#pragma unroll
-            for (int k = 0; k < 6; ++k) ovp[k] = wsld(wsl, base + 12 + k);
-          } else {
-#pragma unroll
-            for (int k = 0; k < 9; ++k) Rp[k] = 0.0;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) tp[k] = 0.0;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) ovp[k] = 0.0;
-          }
-          aba_kin<LAYOUT>(jc, q, vin, root, false, sn, cs, Rp, tp, ovp, R, t, ov, bias);
-          // (s, c) of revolute joints go to the hand-off record for pass 3
-          {
-            const int h = L.hand0 + jc.hand_off + hand_size(jc.nvj) - 2;
-            wsst(wsl, h, sn);
-            wsst(wsl, h + 1, cs);
-          }
-          if (fl & F_PUSH_BRANCH) {
-            const int bs = op_own_bslot(fl);
-            const int kb = L.kb0 + bs * 18;
-#pragma unroll
-            for (int k = 0; k < 9; ++k) wsst(wsl, kb + k, R[k]);
-#pragma unroll
-            for (int k = 0; k < 3; ++k) wsst(wsl, kb + 9 + k, t[k]);
-#pragma unroll
-            for (int k = 0; k < 6; ++k) wsst(wsl, kb + 12 + k, ov[k]);
-            // accumulator starts with the joint's own inertia and bias force (aba.hxx:134-138)
-            aba_own_inertia(jc, R, t, ov, Ia, of);
-            const int ac = L.acc0 + bs * 27;
-#pragma unroll
-            for (int k = 0; k < 21; ++k) wsst(wsl, ac + k, Ia[k]);
-#pragma unroll
-            for (int k = 0; k < 6; ++k) wsst(wsl, ac + 21 + k, of[k]);
-          }
-          if (!(fl & F_LEAF)) {
-            const int base = L.kin0 + op.depth * 18;
-#pragma unroll
-            for (int k = 0; k < 9; ++k) wsst(wsl, base + k, R[k]);
-#pragma unroll
-            for (int k = 0; k < 3; ++k) wsst(wsl, base + 9 + k, t[k]);
-#pragma unroll
-            for (int k = 0; k < 6; ++k) wsst(wsl, base + 12 + k, ov[k]);
-            continue;
-          }
-          aba_own_inertia(jc, R, t, ov, Ia, of);
-          // leaf: fall through to the backward arithmetic with (R, t, ov, bias) in registers
-          double J[36];
-          if (jc.nvj == 1) {
-            jcol_1dof(jc, R, t, J);
-            aba_backward<1, LAYOUT>(A, jc, wsl, L.hand0, root, valid, J, bias, tauin, ddq, Ia, of);
-          } else if (jc.nvj == 6) {
-            jcols_multi<6>(R, t, J);
-            aba_backward<6, LAYOUT>(A, jc, wsl, L.hand0, root, valid, J, bias, tauin, ddq, Ia, of);
-          } else {
-            jcols_multi<3>(R, t, J);
-            aba_backward<3, LAYOUT>(A, jc, wsl, L.hand0, root, valid, J, bias, tauin, ddq, Ia, of);
-          }
-        } else {
-          // ---------------- backward visit of a non-leaf joint (aba.hxx:153-193) ----------------
-          double Rb[9], tb[3], ovb[6];
-          const int base = L.kin0 + op.depth * 18;
-#pragma unroll
-          for (int k = 0; k < 9; ++k) Rb[k] = wsld(wsl, base + k);
-#pragma unroll
-          for (int k = 0; k < 3; ++k) tb[k] = wsld(wsl, base + 9 + k);
-#pragma unroll
-          for (int k = 0; k < 6; ++k) ovb[k] = wsld(wsl, base + 12 + k);
-          double J[36], vJ[6], ovJ[6];
-          // bias = ov_parent x ov with ov_parent = ov - oMi.act(vJ) (aba.hxx:126-132)
-          joint_S_times<LAYOUT>(jc, vin, vJ);
-          se3_act_motion(Rb, tb, vJ, ovJ);
-          if (root) {
-#pragma unroll
-            for (int k = 0; k < 6; ++k) bias[k] = 0.0;
-          } else {
-            double ovp[6];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) ovp[k] = ovb[k] - ovJ[k];
-            motion_cross(ovp, ovb, bias);
-          }
-          if (fl & F_MULTI) {
-            const int ac = L.acc0 + op_own_bslot(fl) * 27;
-#pragma unroll
-            for (int k = 0; k < 21; ++k) Ia[k] = wsld(wsl, ac + k);
-#pragma unroll
-            for (int k = 0; k < 6; ++k) of[k] = wsld(wsl, ac + 21 + k);
-          } else {
-            aba_own_inertia(jc, Rb, tb, ovb, Ia, of);
-#pragma unroll
-            for (int k = 0; k < 21; ++k) Ia[k] += cIa[k];  // aba.hxx:190-191 (single child)
-#pragma unroll
-            for (int k = 0; k < 6; ++k) of[k] += cof[k];
-          }
-          if (jc.nvj == 1) {
-            jcol_1dof(jc, Rb, tb, J);
-            aba_backward<1, LAYOUT>(A, jc, wsl, L.hand0, root, valid, J, bias, tauin, ddq, Ia, of);
-          } else if (jc.nvj == 6) {
-            jcols_multi<6>(Rb, tb, J);
-            aba_backward<6, LAYOUT>(A, jc, wsl, L.hand0, root, valid, J, bias, tauin, ddq, Ia, of);
-          } else {
-            jcols_multi<3>(Rb, tb, J);
-            aba_backward<3, LAYOUT>(A, jc, wsl, L.hand0, root, valid, J, bias, tauin, ddq, Ia, of);
-          }
-        }
-        // ---- hand the articulated contribution to the parent (aba.hxx:190-191) ----
-        if (!root) {
-          if (fl & F_CARRY_REGS) {
-#pragma unroll
-            for (int k = 0; k < 21; ++k) cIa[k] = Ia[k];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) cof[k] = of[k];
-          } else {
-            const int ac = L.acc0 + op.bslot * 27;  // parent's accumulator
-#pragma unroll
-            for (int k = 0; k < 21; ++k) wsst(wsl, ac + k, wsld(wsl, ac + k) + Ia[k]);
-#pragma unroll
-            for (int k = 0; k < 6; ++k) wsst(wsl, ac + 21 + k, wsld(wsl, ac + 21 + k) + of[k]);
-          }
-        }
-      }
-    }
-
-    // ------------------------------------------------ pass 3 (aba.hxx:207-232), forward
-    {
-      double R[9], t[3], ov[6], acc[6];
-#pragma unroll
-      for (int k = 0; k < 9; ++k) R[k] = 0.0;
-#pragma unroll
-      for (int k = 0; k < 3; ++k) t[k] = 0.0;
-#pragma unroll
-      for (int k = 0; k < 6; ++k) ov[k] = acc[k] = 0.0;
-      for (int s = 0; s < A.nops3; ++s) {
-        const Op op = load_op(A.prog3, s);
-        JointConst jc;
-      load_joint(A.tab, op.joint, jc);
-        const int fl = op.flags;
-        const bool root = fl & F_PARENT_ROOT;
-        double Rp[9], tp[3], ovp[6], ap[6];
-        if (root) {
-#pragma unroll
-          for (int k = 0; k < 9; ++k) Rp[k] = 0.0;
-#pragma unroll
-          for (int k = 0; k < 3; ++k) tp[k] = 0.0;
-#pragma unroll
-          for (int k = 0; k < 6; ++k) ovp[k] = ap[k] = 0.0;
-          ap[0] = -A.gx; ap[1] = -A.gy; ap[2] = -A.gz;  // aba.hxx:261
-        } else if (fl & F_FROM_REGS) {
-#pragma unroll
-          for (int k = 0; k < 9; ++k) Rp[k] = R[k];
-#pragma unroll
-          for (int k = 0; k < 3; ++k) tp[k] = t[k];
-#pragma unroll
-          for (int k = 0; k < 6; ++k) { ovp[k] = ov[k]; ap[k] = acc[k]; }
-        } else {
-          const int base = L.k30 + op.bslot * 24;
-#pragma unroll
-          for (int k = 0; k < 9; ++k) Rp[k] = wsld(wsl, base + k);
-#pragma unroll
-          for (int k = 0; k < 3; ++k) tp[k] = wsld(wsl, base + 9 + k);
-#pragma unroll
-          for (int k = 0; k < 6; ++k) { ovp[k] = wsld(wsl, base + 12 + k); ap[k] = wsld(wsl, base + 18 + k); }
-        }
-        const int h = L.hand0 + jc.hand_off;
-        double sn = wsld(wsl, h + hand_size(jc.nvj) - 2);
-        double cs = wsld(wsl, h + hand_size(jc.nvj) - 1);
-        double bias[6];
-        aba_kin<LAYOUT>(jc, q, vin, root, true, sn, cs, Rp, tp, ovp, R, t, ov, bias);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) acc[k] = ap[k] + bias[k];  // :223 (oa_gf[i] += oa_gf[parent])
-        const int iv = jc.idx_v;
-        const bool leaf = fl & F_LEAF;
-        if (jc.nvj == 1) {
-          double dd;
-          if (root) {
-            dd = ddq.get(iv);  // written by the backward visit of this lane
-          } else {
-            double UD[6];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) UD[k] = wsld(wsl, h + k);
-            dd = wsld(wsl, h + 6) - dot6(UD, acc);  // :224-226
-            if (valid) ddq.put(iv, dd);
-          }
-          if (!leaf) {
-            double J[6];
-            jcol_1dof(jc, R, t, J);
-#pragma unroll
-            for (int k = 0; k < 6; ++k) acc[k] += J[k] * dd;  // :227
-          }
-        } else if (jc.nvj == 6) {
-          double dd[6], J[36];
-          if (root) {
-#pragma unroll
-            for (int r = 0; r < 6; ++r) dd[r] = ddq.get(iv + r);
-          } else {
-#pragma unroll
-            for (int r = 0; r < 6; ++r) {
-              double sum = 0.0;
-#pragma unroll
-              for (int c = 0; c < 6; ++c) sum += wsld(wsl, h + 36 + 6 * r + c) * wsld(wsl, h + 72 + c);
-#pragma unroll
-              for (int k = 0; k < 6; ++k) sum -= wsld(wsl, h + 6 * r + k) * acc[k];
-              dd[r] = sum;
-              if (valid) ddq.put(iv + r, sum);
-            }
-          }
-          jcols_multi<6>(R, t, J);
-#pragma unroll
-          for (int c = 0; c < 6; ++c)
-#pragma unroll
-            for (int k = 0; k < 6; ++k) acc[k] += J[6 * c + k] * dd[c];
-        } else {
-          double dd[3], J[18];
-          if (root) {
-#pragma unroll
-            for (int r = 0; r < 3; ++r) dd[r] = ddq.get(iv + r);
-          } else {
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-              double sum = 0.0;
-#pragma unroll
-              for (int c = 0; c < 3; ++c) sum += wsld(wsl, h + 18 + 3 * r + c) * wsld(wsl, h + 27 + c);
-#pragma unroll
-              for (int k = 0; k < 6; ++k) sum -= wsld(wsl, h + 6 * r + k) * acc[k];
-              dd[r] = sum;
-              if (valid) ddq.put(iv + r, sum);
-            }
-          }
-          jcols_multi<3>(R, t, J);
-#pragma unroll
-          for (int c = 0; c < 3; ++c)
-#pragma unroll
-            for (int k = 0; k < 6; ++k) acc[k] += J[6 * c + k] * dd[c];
-        }
-        if (fl & F_PUSH_BRANCH) {
-          const int base = L.k30 + op_own_bslot(fl) * 24;
-#pragma unroll
-          for (int k = 0; k < 9; ++k) wsst(wsl, base + k, R[k]);
-#pragma unroll
-          for (int k = 0; k < 3; ++k) wsst(wsl, base + 9 + k, t[k]);
-#pragma unroll
-          for (int k = 0; k < 6; ++k) { wsst(wsl, base + 12 + k, ov[k]); wsst(wsl, base + 18 + k, acc[k]); }
-        }
-      }
-    }
+    const Mat<LAYOUT> q(const_cast<double*>(A.q), A.ldq, tile, A.B, lane);
+    const Mat<LAYOUT> vin(const_cast<double*>(A.v), A.ldv, tile, A.B, lane);
+    const Mat<LAYOUT> tauin(const_cast<double*>(A.a), A.lda, tile, A.B, lane);
+    const Mat<LAYOUT> ddq(A.out, A.ldout, tile, A.B, lane);
+    AbaState st;
+    aba_state_init(st);
+    for (int s = 0; s < A.nops; ++s) aba_step12(A, load_op(A.prog, s), L, S, H, q, vin, tauin, ddq, st);
+    Aba3State st3;
+    aba3_state_init(st3);
+    for (int s = 0; s < A.nops3; ++s) aba_step3(A, load_op(A.prog3, s), L, S, H, q, vin, ddq, st3);
   }
 }
 
 // =================================================================================== FK + Jacobians
 // forwardKinematics(q) (kinematics.hxx:52-97) + computeJointJacobians(q) (jacobian.hxx:38-95).
-// workspace: KB[bslot][12] = oMi of branching joints.  Chains (arms) never touch the workspace.
+// live state: KB[bslot][12] = oMi of branching joints.  Chains (arms) never spill.
+struct FkState {
+  double R[9], t[3];
+};
+template <class MatT, class Stack>
+DI void fkjac_step(const KArgs& A, const Op op, Stack& S, const MatT& q, const MatT& Jout, const MatT& Mout,
+                   bool wantJ, bool wantM, FkState& st) {
+  JointConst jc;
+  load_joint(A.tab, op.joint, jc);
+  const int fl = op.flags;
+  const bool root = fl & F_PARENT_ROOT;
+  double Rl[9], tl[3], sn, cs;
+  joint_liMi(jc, op, q, false, sn, cs, Rl, tl);
+  if (root) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) st.R[k] = Rl[k];
+    st.t[0] = tl[0]; st.t[1] = tl[1]; st.t[2] = tl[2];
+  } else {
+    double Rp[9], tp[3], Rt[3];
+    if (fl & F_FROM_REGS) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) Rp[k] = st.R[k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) tp[k] = st.t[k];
+    } else {
+      const int base = op.bslot * 12;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) Rp[k] = S.ld(base + k);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) tp[k] = S.ld(base + 9 + k);
+    }
+    rot_mul(Rp, Rl, st.R);
+    rot_vec(Rp, tl, Rt);
+    st.t[0] = tp[0] + Rt[0]; st.t[1] = tp[1] + Rt[1]; st.t[2] = tp[2] + Rt[2];
+  }
+  if (fl & F_PUSH_BRANCH) {
+    const int base = op_own_bslot(fl) * 12;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) S.st(base + k, st.R[k]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) S.st(base + 9 + k, st.t[k]);
+  }
+  if (wantM) {
+    const int o = 12 * op.joint;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) Mout.put(o + 3 * c + r, st.R[3 * r + c]);  // column-major rotation
+    Mout.put(o + 9, st.t[0]); Mout.put(o + 10, st.t[1]); Mout.put(o + 11, st.t[2]);
+  }
+  if (wantJ) {
+    const int o = 6 * op.idx_v;
+    if (op.nvj == 1) {
+      double J[6];
+      jcol_1dof(op, st.R, st.t, J);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) Jout.put(o + k, J[k]);
+    } else if (op.nvj == 6) {
+      double J[36];
+      jcols_multi<6>(st.R, st.t, J);
+#pragma unroll
+      for (int k = 0; k < 36; ++k) Jout.put(o + k, J[k]);
+    } else {
+      double J[18];
+      jcols_multi<3>(st.R, st.t, J);
+#pragma unroll
+      for (int k = 0; k < 18; ++k) Jout.put(o + k, J[k]);
+    }
+  }
+}
+
 template <int LAYOUT>
 __global__ __launch_bounds__(WAVE) void fkjac_kernel(const KArgs A) {
   const int lane = threadIdx.x;
-  double* const wsl = A.ws + (int64_t)blockIdx.x * A.ws_stride + lane;
+  GlobalStore S(A.ws + (int64_t)blockIdx.x * A.ws_stride, (unsigned)lane);
+  const bool wantJ = A.out != nullptr, wantM = A.out2 != nullptr;
   for (int64_t tile = blockIdx.x; tile < A.ntiles; tile += gridDim.x) {
-    const int64_t b0 = tile * WAVE + lane;
-    const bool valid = b0 < A.B;
-    const int64_t b = valid ? b0 : A.B - 1;
-    const Mat<LAYOUT> q{const_cast<double*>(A.q), A.ldq, b};
-    const Mat<LAYOUT> Jout{A.out, A.ldout, b};
-    const Mat<LAYOUT> Mout{A.out2, A.ldout2, b};
-    const bool wantJ = A.out != nullptr, wantM = A.out2 != nullptr;
-    if (wantM && valid) {  // joint 0 = identity
+    const Mat<LAYOUT> q(const_cast<double*>(A.q), A.ldq, tile, A.B, lane);
+    const Mat<LAYOUT> Jout(A.out, A.ldout, tile, A.B, lane);
+    const Mat<LAYOUT> Mout(A.out2, A.ldout2, tile, A.B, lane);
+    if (wantM) {  // joint 0 = identity
 #pragma unroll
       for (int k = 0; k < 12; ++k) Mout.put(k, (k == 0 || k == 4 || k == 8) ? 1.0 : 0.0);
     }
-    double R[9], t[3];
+    FkState st;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) R[k] = 0.0;
+    for (int k = 0; k < 9; ++k) st.R[k] = 0.0;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) t[k] = 0.0;
-    for (int s = 0; s < A.nops3; ++s) {
-      const Op op = load_op(A.prog3, s);
-      JointConst jc;
-      load_joint(A.tab, op.joint, jc);
-      const int fl = op.flags;
-      const bool root = fl & F_PARENT_ROOT;
-      double Rl[9], tl[3], sn, cs;
-      joint_liMi<LAYOUT>(jc, q, false, sn, cs, Rl, tl);
-      if (root) {
-#pragma unroll
-        for (int k = 0; k < 9; ++k) R[k] = Rl[k];
-        t[0] = tl[0]; t[1] = tl[1]; t[2] = tl[2];
-      } else {
-        double Rp[9], tp[3], Rt[3];
-        if (fl & F_FROM_REGS) {
-#pragma unroll
-          for (int k = 0; k < 9; ++k) Rp[k] = R[k];
-#pragma unroll
-          for (int k = 0; k < 3; ++k) tp[k] = t[k];
-        } else {
-          const int base = op.bslot * 12;
-#pragma unroll
-          for (int k = 0; k < 9; ++k) Rp[k] = wsld(wsl, base + k);
-#pragma unroll
-          for (int k = 0; k < 3; ++k) tp[k] = wsld(wsl, base + 9 + k);
-        }
-        rot_mul(Rp, Rl, R);
-        rot_vec(Rp, tl, Rt);
-        t[0] = tp[0] + Rt[0]; t[1] = tp[1] + Rt[1]; t[2] = tp[2] + Rt[2];
-      }
-      if (fl & F_PUSH_BRANCH) {
-        const int base = op_own_bslot(fl) * 12;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) wsst(wsl, base + k, R[k]);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) wsst(wsl, base + 9 + k, t[k]);
-      }
-      if (wantM && valid) {
-        const int o = 12 * op.joint;
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-          for (int c = 0; c < 3; ++c) Mout.put(o + 3 * c + r, R[3 * r + c]);  // column-major rotation
-        Mout.put(o + 9, t[0]); Mout.put(o + 10, t[1]); Mout.put(o + 11, t[2]);
-      }
-      if (wantJ && valid) {
-        const int o = 6 * jc.idx_v;
-        if (jc.nvj == 1) {
-          double J[6];
-          jcol_1dof(jc, R, t, J);
-#pragma unroll
-          for (int k = 0; k < 6; ++k) Jout.put(o + k, J[k]);
-        } else if (jc.nvj == 6) {
-          double J[36];
-          jcols_multi<6>(R, t, J);
-#pragma unroll
-          for (int k = 0; k < 36; ++k) Jout.put(o + k, J[k]);
-        } else {
-          double J[18];
-          jcols_multi<3>(R, t, J);
-#pragma unroll
-          for (int k = 0; k < 18; ++k) Jout.put(o + k, J[k]);
-        }
-      }
-    }
+    for (int k = 0; k < 3; ++k) st.t[k] = 0.0;
+    for (int s = 0; s < A.nops3; ++s) fkjac_step(A, load_op(A.prog3, s), S, q, Jout, Mout, wantJ, wantM, st);
   }
 }
 

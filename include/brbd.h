@@ -168,13 +168,14 @@ int brbd_transpose_to_batch_major(int device, int64_t dof, int64_t B, const doub
 int brbd_transpose_to_instance_major(int device, int64_t dof, int64_t B, const double* src,
                                      int64_t ld_src, double* dst, int64_t ld_dst, void* stream);
 
-/* Topology-specialised kernels.  Topologies registered at build time
- * (tools/gen_static_models.py -> pinocchio_amd/csrc/brbd_static_models.inc) get unrolled,
- * register-resident kernels; brbd_model_create selects them automatically when the model's
- * depth-first program matches a registered one exactly (any placements / inertias), every other
- * model runs on the generic table-driven kernels.  brbd_model_static_topology returns the name of
- * the matched topology ("" = generic); brbd_model_use_static(m, 0) forces the generic kernels
- * (used by the tests to check both paths against the oracle).  No reference counterpart. */
+/* Topology-specialised kernels (EXPERIMENTAL, off by default).  Topologies registered at build
+ * time (tools/gen_static_models.py -> pinocchio_amd/csrc/brbd_static_models.inc) also get
+ * unrolled, register-resident instantiations of the same step functions.  They are selected
+ * only when the model's depth-first program matches a registered one exactly AND the caller
+ * opts in (brbd_model_use_static(m, 1) or BRBD_ENABLE_STATIC=1): on ROCm 7.2 hipcc's register
+ * allocation of the unrolled stream is worse than the table-driven kernels.
+ * brbd_model_static_topology returns the matched topology name ("" = none).
+ * No reference counterpart. */
 const char* brbd_model_static_topology(const brbd_model* m);
 int brbd_model_use_static(brbd_model* m, int enabled);
 

@@ -61,7 +61,8 @@ struct brbd_model {
   int max_waves[4] = {0, 0, 0, 0};
   int max_waves_static[4] = {0, 0, 0, 0};
   const StaticEntry* stat = nullptr;  // unrolled kernels for this topology, if registered
-  bool use_static = true;
+  bool use_static = false;  // opt-in: BRBD_ENABLE_STATIC=1 or brbd_model_use_static(m, 1)
+  bool use_lds = true;
   bool timing = false;
   std::vector<TimedLaunch> timed[4];
   std::mutex mu;
@@ -171,18 +172,15 @@ int launch_algo(brbd_model* m, int algo, KArgs& A, int layout, hipStream_t strea
   if (A.B == 0) return BRBD_OK;
   int per_lane = 0;
   switch (algo) {
-    case BRBD_ALGO_RNEA: per_lane = F.ws_rnea(); break;
+    case BRBD_ALGO_RNEA: per_lane = F.stack_rnea(); break;
     case BRBD_ALGO_ABA: per_lane = F.ws_aba(); break;
     case BRBD_ALGO_FK_JAC: per_lane = F.ws_fkjac(); break;
     default: return fail(BRBD_ERR_INVALID_ARGUMENT, "unknown algorithm");
   }
   const bool stat = m->stat && m->use_static && layout == BRBD_BATCH_MAJOR;
   KernelFn sfn = nullptr;
-  if (stat) {
+  if (stat)
     sfn = algo == BRBD_ALGO_RNEA ? m->stat->rnea : (algo == BRBD_ALGO_ABA ? m->stat->aba : m->stat->fkjac);
-    // the unrolled kernels keep the path state in registers: only ABA's hand-off records spill
-    per_lane = algo == BRBD_ALGO_ABA ? F.hand_total : 1;
-  }
   int& mw = stat ? m->max_waves_static[algo] : m->max_waves[algo];
   if (mw == 0) {
     int w = 0;
@@ -190,9 +188,34 @@ int launch_algo(brbd_model* m, int algo, KArgs& A, int layout, hipStream_t strea
     else if (algo == BRBD_ALGO_RNEA) w = resident_waves(m, rnea_kernel<1>, WAVE);
     else if (algo == BRBD_ALGO_ABA) w = resident_waves(m, aba_kernel<1>, WAVE);
     else w = resident_waves(m, fkjac_kernel<1>, WAVE);
-    mw = w;
+    mw = w;  // VGPR-limited resident waves on the whole device
   }
-  int64_t grid = A.ntiles < mw ? A.ntiles : mw;
+  // LDS part of the live-state stack (generic RNEA / ABA): as many slots as fit without lowering
+  // the number of waves per CU below what this launch can use.
+  int lds_cap = 0;
+  size_t lds_bytes = 0;
+  int64_t resident = mw;
+  if (!stat && (algo == BRBD_ALGO_RNEA || algo == BRBD_ALGO_ABA)) {
+    const int stack = algo == BRBD_ALGO_RNEA ? F.stack_rnea() : F.stack_aba();
+    const int64_t per_cu_vgpr = mw / m->num_cu;
+    int64_t want_per_cu = (A.ntiles + m->num_cu - 1) / m->num_cu;
+    if (want_per_cu > per_cu_vgpr) want_per_cu = per_cu_vgpr;
+    if (want_per_cu < 1) want_per_cu = 1;
+    const int64_t lds_per_cu = 160 * 1024;
+    int64_t cap = lds_per_cu / (want_per_cu * WAVE * 8);
+    if (cap > stack) cap = stack;
+    if (cap > 96) cap = 96;  // 48 KiB dynamic LDS per workgroup at most
+    if (!m->use_lds) cap = 0;
+    lds_cap = (int)cap;
+    lds_bytes = (size_t)lds_cap * WAVE * 8;
+    per_lane = (stack - lds_cap) + (algo == BRBD_ALGO_ABA ? F.hand_total : 0);
+    if (per_lane < 1) per_lane = 1;
+  } else if (stat) {
+    // the unrolled kernels keep the path state in registers: only ABA's hand-off records spill
+    per_lane = algo == BRBD_ALGO_ABA ? F.hand_total : 1;
+  }
+  A.lds_cap = lds_cap;
+  int64_t grid = A.ntiles < resident ? A.ntiles : resident;
   A.ws_stride = (int64_t)per_lane * WAVE;
   int rc = ensure_ws(m, (size_t)grid * A.ws_stride);
   if (rc) return rc;
@@ -203,11 +226,11 @@ int launch_algo(brbd_model* m, int algo, KArgs& A, int layout, hipStream_t strea
   if (stat) {
     hipLaunchKernelGGL(sfn, g, b, 0, stream, A);
   } else if (algo == BRBD_ALGO_RNEA) {
-    if (layout == BRBD_BATCH_MAJOR) hipLaunchKernelGGL(rnea_kernel<1>, g, b, 0, stream, A);
-    else hipLaunchKernelGGL(rnea_kernel<0>, g, b, 0, stream, A);
+    if (layout == BRBD_BATCH_MAJOR) hipLaunchKernelGGL(rnea_kernel<1>, g, b, lds_bytes, stream, A);
+    else hipLaunchKernelGGL(rnea_kernel<0>, g, b, lds_bytes, stream, A);
   } else if (algo == BRBD_ALGO_ABA) {
-    if (layout == BRBD_BATCH_MAJOR) hipLaunchKernelGGL(aba_kernel<1>, g, b, 0, stream, A);
-    else hipLaunchKernelGGL(aba_kernel<0>, g, b, 0, stream, A);
+    if (layout == BRBD_BATCH_MAJOR) hipLaunchKernelGGL(aba_kernel<1>, g, b, lds_bytes, stream, A);
+    else hipLaunchKernelGGL(aba_kernel<0>, g, b, lds_bytes, stream, A);
   } else {
     if (layout == BRBD_BATCH_MAJOR) hipLaunchKernelGGL(fkjac_kernel<1>, g, b, 0, stream, A);
     else hipLaunchKernelGGL(fkjac_kernel<0>, g, b, 0, stream, A);
@@ -278,8 +301,10 @@ int brbd_model_create(const brbd_model_desc* desc, int device, brbd_model** out)
       m->stat = &e;
       break;
     }
-    const char* env = getenv("BRBD_DISABLE_STATIC");
-    if (env && env[0] == '1') m->use_static = false;
+    const char* env = getenv("BRBD_ENABLE_STATIC");
+    if (env && env[0] == '1') m->use_static = true;
+    env = getenv("BRBD_DISABLE_LDS");
+    if (env && env[0] == '1') m->use_lds = false;
   }
   auto upload = [&](void** dst, const void* src, size_t bytes) -> hipError_t {
     hipError_t e = hipMalloc(dst, bytes ? bytes : 16);
@@ -330,7 +355,7 @@ int64_t brbd_workspace_bytes(const brbd_model* m, int algo, int64_t B) {
   const FlatModel& F = m->flat;
   int per_lane = 0;
   switch (algo) {
-    case BRBD_ALGO_RNEA: per_lane = F.ws_rnea(); break;
+    case BRBD_ALGO_RNEA: per_lane = F.stack_rnea(); break;
     case BRBD_ALGO_ABA: per_lane = F.ws_aba(); break;
     case BRBD_ALGO_FK_JAC: per_lane = F.ws_fkjac(); break;
     case BRBD_ALGO_RNEA_DERIV: per_lane = deriv_ws_per_lane(F); break;

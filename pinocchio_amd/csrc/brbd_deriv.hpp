@@ -138,10 +138,10 @@ __global__ __launch_bounds__(WAVE) void rnea_deriv_kernel(const DerivArgs A) {
       const int rec = JR0 + DJ_SIZE * i, prec = JR0 + DJ_SIZE * p;
       double Rl[9], tl[3], sn, cs, R[9], t[3];
       const Op op = op_from_joint(jc, i);
-      joint_liMi(jc, op, q, false, sn, cs, Rl, tl);
+      joint_liMi(jc, op, q, q.get(op.idx_q), false, sn, cs, Rl, tl);
       double vJ[6], Sa[6], vloc[6], aloc[6], tmp[6];
-      joint_S_times(op, vin, vJ);
-      joint_S_times(op, ain, Sa);
+      joint_S_times(op, vin, vin.get(op.idx_v), vJ);
+      joint_S_times(op, ain, ain.get(op.idx_v), Sa);
       double ovp[6], oagfp[6];
       if (p > 0) {
         double Rp[9], tp[3], Rt[3], vp[6], ap[6];
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(WAVE) void rnea_deriv_kernel(const DerivArgs A) {
         ld6(W, DC_DADQ * colsz + col, dAdq);
         ld6(W, DC_DADV * colsz + col, dAdv);
         if (wantTau) {  // :409-410 (+ armature, :538-539)
-          const double x = dot6(Jc, of) + jc.arm[c] * ain.get(iv + c);
+          const double x = dot6(Jc, of) + as_constant(A.tab)[i].arm[c] * ain.get(iv + c);
           if (valid) ptau.put(iv + c, x);
         }
         inertia_mul(Ym, Yc, YI, Jc, dFda);  // :419
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(WAVE) void rnea_deriv_kernel(const DerivArgs A) {
           if (wantM) {
             ld6(W, DC_DFDA * colsz + col, x);
             double mval = dot6(Jr, x);
-            if (c == r) mval += jc.arm[r];  // :540
+            if (c == r) mval += as_constant(A.tab)[i].arm[r];  // :540
             if (valid) pda.put(e, mval);
           }
           ld6(W, DC_DFDQ * colsz + col, x);

@@ -100,6 +100,14 @@ DI Op op_from_joint(const JointConst& jc, int joint) {
   return o;
 }
 
+// value select (never a select between addresses, which would defeat scalar replacement)
+DI double sel3(int k, double a, double b, double c) {
+  double r = c;
+  r = (k == 1) ? b : r;
+  r = (k == 0) ? a : r;
+  return r;
+}
+
 // ---- 3-vectors / rotations -------------------------------------------------------------------
 DI void cross3(const double* a, const double* b, double* o) {
   const double x = a[1] * b[2] - a[2] * b[1];

@@ -32,8 +32,9 @@ struct FlatModel {
   std::vector<int> nv_subtree;
 
   // workspace doubles per lane
-  int ws_rnea() const { return maxdepth * 8 + maxbranch * 12; }
-  int ws_aba() const { return maxdepth * 18 + maxbranch * (27 + 18 + 24) + hand_total; }
+  int stack_rnea() const { return maxdepth * 8 + maxbranch * 12; }
+  int stack_aba() const { return maxdepth * 2 + maxbranch * 27; }
+  int ws_aba() const { return stack_aba() + hand_total; }
   int ws_fkjac() const { return maxbranch * 12; }
 };
 

@@ -37,6 +37,8 @@ struct KArgs {
   int64_t B;
   int64_t ntiles;
   double* ws;         // spill workspace
+  int32_t lds_cap;    // live-state slots held in LDS (HybridStore), rest in ws
+  int32_t pad_;
   int64_t ws_stride;  // doubles per wave
   double gx, gy, gz;  // gravity
   const double* q; int64_t ldq;
@@ -104,19 +106,48 @@ struct RegStore {
   DI void st(int slot, double x) { r[slot] = x; }
 };
 
-// ---- joint kinematics: liMi = placement * M(q) ---------------------------------------------------
-// have_sc: (s, c) already known (backward visit / pass 3), skip sincos.
+// HybridStore: the first `cap` slots live in LDS (one 512-byte row per slot, ~100-cycle access
+// instead of an L2 round trip), the rest in the wave-private global workspace.  `cap` is chosen by
+// the host so that the LDS footprint never lowers the occupancy the VGPR budget allows.
+struct HybridStore {
+  double* lds;  // &smem[lane]; slot s at lds[s * 64]
+  int cap;
+  GlobalStore g;
+  DI HybridStore(double* smem, int cap_, double* gbase, unsigned lane) : lds(smem + lane), cap(cap_), g(gbase, lane) {}
+  DI double ld(int slot) const { return slot < cap ? lds[slot * WAVE] : g.ld(slot - cap); }
+  DI void st(int slot, double x) const {
+    if (slot < cap) lds[slot * WAVE] = x;
+    else g.st(slot - cap, x);
+  }
+};
+
+// First element of q, v and a (RNEA) / tau (ABA) of an op's joint, fetched one op ahead of its
+// use so that the HBM latency of the inputs hides behind the previous op's arithmetic.
+struct Pre {
+  double q0, v0, x0;
+};
 template <class MatT>
-DI void joint_liMi(const JointConst& jc, const Op& op, const MatT& q, bool have_sc, double& s, double& c,
-                   double* R, double* t) {
+DI Pre prefetch(const Op& op, const MatT& q, const MatT& v, const MatT& x) {
+  Pre p;
+  p.q0 = q.get(op.idx_q);
+  p.v0 = v.get(op.idx_v);
+  p.x0 = x.get(op.idx_v);
+  return p;
+}
+
+// ---- joint kinematics: liMi = placement * M(q) ---------------------------------------------------
+// have_sc: (s, c) already known (backward visit / pass 3), skip sincos.  q0 = q[idx_q] (prefetched).
+template <class MatT>
+DI void joint_liMi(const JointConst& jc, const Op& op, const MatT& q, double q0, bool have_sc, double& s,
+                   double& c, double* R, double* t) {
   const int jt = op.jtype, iq = op.idx_q;
   switch (jt) {
     case JT_RX: case JT_RY: case JT_RZ: case JT_RUBX: case JT_RUBY: case JT_RUBZ: {
       if (!have_sc) {
         if (jt <= JT_RZ) {
-          sincos(q.get(iq), &s, &c);  // math/sincos.hpp:47-61
+          sincos(q0, &s, &c);  // math/sincos.hpp:47-61
         } else {
-          c = q.get(iq);  // joint-revolute-unbounded.hpp:153-162
+          c = q0;  // joint-revolute-unbounded.hpp:153-162
           s = q.get(iq + 1);
         }
       }
@@ -130,13 +161,12 @@ DI void joint_liMi(const JointConst& jc, const Op& op, const MatT& q, bool have_
     case JT_PX: case JT_PY: case JT_PZ: {
       // joint-prismatic.hpp:262-272
       const int k = jt - JT_PX;
-      const double x = q.get(iq);
 #pragma unroll
       for (int i = 0; i < 9; ++i) R[i] = jc.R[i];
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
-        const double col = k == 0 ? jc.R[3 * r] : (k == 1 ? jc.R[3 * r + 1] : jc.R[3 * r + 2]);
-        t[r] = jc.t[r] + x * col;
+        const double r0 = jc.R[3 * r], r1 = jc.R[3 * r + 1], r2 = jc.R[3 * r + 2];
+        t[r] = jc.t[r] + q0 * sel3(k, r0, r1, r2);
       }
       break;
     }
@@ -144,7 +174,7 @@ DI void joint_liMi(const JointConst& jc, const Op& op, const MatT& q, bool have_
       // joint-free-flyer.hpp:332-374
       double Rq[9], p[3], Rp[3];
       quat_to_R(q.get(iq + 3), q.get(iq + 4), q.get(iq + 5), q.get(iq + 6), Rq);
-      p[0] = q.get(iq); p[1] = q.get(iq + 1); p[2] = q.get(iq + 2);
+      p[0] = q0; p[1] = q.get(iq + 1); p[2] = q.get(iq + 2);
       rot_mul(jc.R, Rq, R);
       rot_vec(jc.R, p, Rp);
       t[0] = jc.t[0] + Rp[0]; t[1] = jc.t[1] + Rp[1]; t[2] = jc.t[2] + Rp[2];
@@ -152,7 +182,7 @@ DI void joint_liMi(const JointConst& jc, const Op& op, const MatT& q, bool have_
     }
     default: {  // JT_SPH, joint-spherical.hpp:525-589
       double Rq[9];
-      quat_to_R(q.get(iq), q.get(iq + 1), q.get(iq + 2), q.get(iq + 3), Rq);
+      quat_to_R(q0, q.get(iq + 1), q.get(iq + 2), q.get(iq + 3), Rq);
       rot_mul(jc.R, Rq, R);
       t[0] = jc.t[0]; t[1] = jc.t[1]; t[2] = jc.t[2];
       break;
@@ -160,21 +190,21 @@ DI void joint_liMi(const JointConst& jc, const Op& op, const MatT& q, bool have_
   }
 }
 
-// Dense S * x for the joint (x = joint velocity or acceleration read from `m`)
+// Dense S * x for the joint (x = joint velocity or acceleration read from `m`; x0 = m[idx_v])
 template <class MatT>
-DI void joint_S_times(const Op& op, const MatT& m, double* o) {
+DI void joint_S_times(const Op& op, const MatT& m, double x0, double* o) {
   const int iv = op.idx_v;
   if (op.nvj == 1) {
-    const double x = m.get(iv);
     const int comp = op.comp;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) o[k] = (k == comp) ? x : 0.0;
+    for (int k = 0; k < 6; ++k) o[k] = (k == comp) ? x0 : 0.0;
   } else if (op.nvj == 6) {
+    o[0] = x0;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) o[k] = m.get(iv + k);
+    for (int k = 1; k < 6; ++k) o[k] = m.get(iv + k);
   } else {
     o[0] = o[1] = o[2] = 0.0;
-    o[3] = m.get(iv); o[4] = m.get(iv + 1); o[5] = m.get(iv + 2);
+    o[3] = x0; o[4] = m.get(iv + 1); o[5] = m.get(iv + 2);
   }
 }
 
@@ -189,8 +219,8 @@ DI void rnea_state_init(RneaState& st) {
 }
 
 template <class MatT, class Stack>
-DI void rnea_step(const KArgs& A, const Op op, Stack& S, const int VA0, const MatT& q, const MatT& vin,
-                  const MatT& ain, const MatT& tau, RneaState& st) {
+DI void rnea_step(const KArgs& A, const Op op, const Pre pre, Stack& S, const int VA0, const MatT& q,
+                  const MatT& vin, const MatT& ain, const MatT& tau, RneaState& st) {
   JointConst jc;
   load_joint(A.tab, op.joint, jc);
   const int fl = op.flags;
@@ -210,10 +240,10 @@ DI void rnea_step(const KArgs& A, const Op op, Stack& S, const int VA0, const Ma
 #pragma unroll
       for (int k = 0; k < 6; ++k) { vp[k] = S.ld(base + k); ap[k] = S.ld(base + 6 + k); }
     }
-    joint_liMi(jc, op, q, false, sn, cs, R, t);
+    joint_liMi(jc, op, q, pre.q0, false, sn, cs, R, t);
     double vJ[6], Sa[6], tmp[6];
-    joint_S_times(op, vin, vJ);
-    joint_S_times(op, ain, Sa);
+    joint_S_times(op, vin, pre.v0, vJ);
+    joint_S_times(op, ain, pre.x0, Sa);
     if (fl & F_PARENT_ROOT) {  // :63-65, velocity propagation guarded by parent > 0
 #pragma unroll
       for (int k = 0; k < 6; ++k) st.v[k] = vJ[k];
@@ -256,7 +286,7 @@ DI void rnea_step(const KArgs& A, const Op op, Stack& S, const int VA0, const Ma
 #pragma unroll
       for (int k = 0; k < 6; ++k) f[k] += st.carry[k];
     }
-    joint_liMi(jc, op, q, true, sn, cs, R, t);
+    joint_liMi(jc, op, q, pre.q0, true, sn, cs, R, t);
   }
   // ---- common tail: tau = S^T f (+ armature * a), hand f to the parent ----
   const int iv = op.idx_v;
@@ -264,8 +294,11 @@ DI void rnea_step(const KArgs& A, const Op op, Stack& S, const int VA0, const Ma
     const int comp = op.comp;
     double x = f[0];
 #pragma unroll
-    for (int k = 1; k < 6; ++k) x = (k == comp) ? f[k] : x;
-    x += jc.arm[0] * ain.get(iv);  // rnea.hxx:158
+    for (int k = 1; k < 6; ++k) {
+      const double fk = f[k];
+      x = (k == comp) ? fk : x;
+    }
+    x += jc.arm[0] * pre.x0;  // rnea.hxx:158
     tau.put(iv, x);
   } else if (op.nvj == 6) {
 #pragma unroll
@@ -288,10 +321,12 @@ DI void rnea_step(const KArgs& A, const Op op, Stack& S, const int VA0, const Ma
   }
 }
 
+extern __shared__ double brbd_smem[];
+
 template <int LAYOUT>
 __global__ __launch_bounds__(WAVE) void rnea_kernel(const KArgs A) {
   const int lane = threadIdx.x;
-  GlobalStore S(A.ws + (int64_t)blockIdx.x * A.ws_stride, (unsigned)lane);
+  HybridStore S(brbd_smem, A.lds_cap, A.ws + (int64_t)blockIdx.x * A.ws_stride, (unsigned)lane);
   const int VA0 = A.maxdepth * 8;
   for (int64_t tile = blockIdx.x; tile < A.ntiles; tile += gridDim.x) {
     const Mat<LAYOUT> q(const_cast<double*>(A.q), A.ldq, tile, A.B, lane);
@@ -300,7 +335,15 @@ __global__ __launch_bounds__(WAVE) void rnea_kernel(const KArgs A) {
     const Mat<LAYOUT> tau(A.out, A.ldout, tile, A.B, lane);
     RneaState st;
     rnea_state_init(st);
-    for (int s = 0; s < A.nops; ++s) rnea_step(A, load_op(A.prog, s), S, VA0, q, vin, ain, tau, st);
+    Op op = load_op(A.prog, 0);
+    Pre pre = prefetch(op, q, vin, ain);
+    for (int s = 0; s < A.nops; ++s) {
+      const Op nxt = load_op(A.prog, s + 1 < A.nops ? s + 1 : s);
+      const Pre pn = prefetch(nxt, q, vin, ain);
+      rnea_step(A, op, pre, S, VA0, q, vin, ain, tau, st);
+      op = nxt;
+      pre = pn;
+    }
   }
 }
 
@@ -312,7 +355,12 @@ DI void jcol_1dof(const Op& op, const double* R, const double* t, double* J) {
   const int k = comp >= 3 ? comp - 3 : comp;
   double col[3];
 #pragma unroll
-  for (int r = 0; r < 3; ++r) col[r] = k == 0 ? R[3 * r] : (k == 1 ? R[3 * r + 1] : R[3 * r + 2]);
+  for (int r = 0; r < 3; ++r) {
+    // select among VALUES: a ternary on the array lvalues becomes a dynamically indexed load and
+    // drags the whole state struct into scratch memory
+    const double r0 = R[3 * r], r1 = R[3 * r + 1], r2 = R[3 * r + 2];
+    col[r] = sel3(k, r0, r1, r2);
+  }
   if (comp >= 3) {
     cross3(t, col, J);
     J[3] = col[0]; J[4] = col[1]; J[5] = col[2];
@@ -341,34 +389,18 @@ DI void jcols_multi(const double* R, const double* t, double* J /* NV x 6 */) {
   }
 }
 
-// world kinematics of one joint from its parent's (oMp, ovp): oMi, ov, bias = ovp x ov
-// (aba.hxx:115-132).  root: parent == 0.
-template <class MatT>
-DI void aba_kin(const JointConst& jc, const Op& op, const MatT& q, const MatT& vin, bool root,
-                bool have_sc, double& sn, double& cs, const double* Rp, const double* tp,
-                const double* ovp, double* R, double* t, double* ov, double* bias) {
-  double Rl[9], tl[3];
-  joint_liMi(jc, op, q, have_sc, sn, cs, Rl, tl);
+// oMi = oMp * liMi (se3-tpl.hpp:311-315); root: oMi = liMi (aba.hxx:119-122)
+DI void compose(bool root, const double* Rp, const double* tp, const double* Rl, const double* tl, double* R,
+                double* t) {
   if (root) {
 #pragma unroll
     for (int i = 0; i < 9; ++i) R[i] = Rl[i];
     t[0] = tl[0]; t[1] = tl[1]; t[2] = tl[2];
-  } else {  // se3-tpl.hpp:311-315
+  } else {
     double Rt[3];
     rot_mul(Rp, Rl, R);
     rot_vec(Rp, tl, Rt);
     t[0] = tp[0] + Rt[0]; t[1] = tp[1] + Rt[1]; t[2] = tp[2] + Rt[2];
-  }
-  double vJ[6], ovJ[6];
-  joint_S_times(op, vin, vJ);
-  se3_act_motion(R, t, vJ, ovJ);  // aba.hxx:126
-  if (root) {
-#pragma unroll
-    for (int k = 0; k < 6; ++k) { ov[k] = ovJ[k]; bias[k] = 0.0; }
-  } else {
-#pragma unroll
-    for (int k = 0; k < 6; ++k) ov[k] = ovJ[k] + ovp[k];  // :127-128
-    motion_cross(ovp, ov, bias);                           // :131-132
   }
 }
 
@@ -382,23 +414,26 @@ DI void aba_own_inertia(const JointConst& jc, const double* R, const double* t, 
   force_cross(ov, h, of);
 }
 
-// live-state slots per lane (ABA), "stack" part:
-//   KIN[depth][18]   = oMi (R 9, t 3) + ov (6)        (non-leaf joints, forward -> backward visit)
-//   ACC[bslot][27]   = Ia (21) + of (6)               (branching joints: own + children)
-//   KB[bslot][18]    = oMi + ov of a branching joint  (for its 2nd.. children, pass 1)
-//   K3[bslot][24]    = oMi + ov + a of a branching joint (pass 3)
+// live-state slots per lane (ABA), "stack" part (LDS first, see HybridStore):
+//   SC[depth][2]     = (sin, cos) of the non-leaf joints on the current root path
+//   ACC[bslot][27]   = Ia (21) + of (6) of the branching joints on the path: own + children so far;
+//                      pass 3 reuses the same rows for K3[bslot][24] = oMi (12) + ov (6) + a (6)
 // and, always in the global workspace (it lives from pass 2 to pass 3 for every joint):
 //   HAND[...]        = per joint hand-off record (hand_off from the flattener)
+//
+// The world placement oMi and velocity ov of the joints on the path are NOT stacked: on the way
+// back up they are recovered from the child's by undoing the composition
+//   oMp = oMi * liMi^-1,  ov_p = ov_i - oMi.act(vJ_i)
+// (45 flops instead of an 18-double round trip through memory per joint; the difference to the
+// values of the forward sweep is rounding-level, ~1e-16 per joint).
 struct AbaLayout {
-  int kin0, acc0, kb0, k30, end;
+  int sc0, acc0, end;
 };
 __host__ __device__ constexpr AbaLayout aba_layout(int maxdepth, int maxbranch) {
   AbaLayout L{};
-  L.kin0 = 0;
-  L.acc0 = L.kin0 + maxdepth * 18;
-  L.kb0 = L.acc0 + maxbranch * 27;
-  L.k30 = L.kb0 + maxbranch * 18;
-  L.end = L.k30 + maxbranch * 24;
+  L.sc0 = 0;
+  L.acc0 = L.sc0 + maxdepth * 2;
+  L.end = L.acc0 + maxbranch * 27;
   return L;
 }
 
@@ -412,12 +447,12 @@ __host__ __device__ constexpr int hand_size(int nvj) {
 // exit.  Writes the pass-3 hand-off record, or ddq directly for joints attached to the universe.
 template <int NV, class MatT>
 DI void aba_backward(const KArgs& A, const JointConst& jc, const Op& op, const GlobalStore& H, bool root,
-                     const double* J, const double* bias, const MatT& tauin, const MatT& ddq, double* Ia,
-                     double* of) {
+                     const double* J, const double* bias, const MatT& tauin, double tau0, const MatT& ddq,
+                     double* Ia, double* of) {
   const int iv = op.idx_v;
   double u[NV], U[NV * 6], D[NV * NV], Dinv[NV * NV], UD[NV * 6];
 #pragma unroll
-  for (int c = 0; c < NV; ++c) u[c] = tauin.get(iv + c) - dot6(J + 6 * c, of);  // :173 (u = tau)
+  for (int c = 0; c < NV; ++c) u[c] = (c == 0 ? tau0 : tauin.get(iv + c)) - dot6(J + 6 * c, of);  // :173
 #pragma unroll
   for (int c = 0; c < NV; ++c) sym6_mulvec(Ia, J + 6 * c, U + 6 * c);  // :175
 #pragma unroll
@@ -488,27 +523,118 @@ DI void aba_backward(const KArgs& A, const JointConst& jc, const Op& op, const G
   }
 }
 
+// Joints attached to the universe (typically the free-flyer): no parent to update and
+// a = a_gf[0] + bias(= 0) = -gravity is already known, so pass 3 of the joint collapses into the
+// backward visit: ddq = Dinv (u - U^T a) (aba.hxx:173-181,223-226), solved by a Cholesky
+// factorisation of D = J^T Ia J + armature without forming Dinv / UDinv.
+template <int NV, class MatT>
+DI void aba_root_solve(const KArgs& A, const JointConst& jc, const Op& op, const double* J, const MatT& tauin,
+                       double tau0, const MatT& ddq, const double* Ia, const double* of) {
+  const int iv = op.idx_v;
+  double U[NV * 6], L[NV * NV], x[NV];
+  const double a0[6] = {-A.gx, -A.gy, -A.gz, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int c = 0; c < NV; ++c) {
+    sym6_mulvec(Ia, J + 6 * c, U + 6 * c);
+    x[c] = ((c == 0 ? tau0 : tauin.get(iv + c)) - dot6(J + 6 * c, of)) - dot6(U + 6 * c, a0);
+  }
+  // Cholesky D = L L^T, lower triangle, row-major
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    double d = dot6(J + 6 * j, U + 6 * j) + jc.arm[j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) d -= L[NV * j + k] * L[NV * j + k];
+    const double rd = NV == 1 ? 1.0 / d : rsqrt(d);
+    L[NV * j + j] = rd;  // 1 / L_jj (NV == 1: 1 / D)
+#pragma unroll
+    for (int i = j + 1; i < NV; ++i) {
+      double sv = dot6(J + 6 * i, U + 6 * j);
+#pragma unroll
+      for (int k = 0; k < j; ++k) sv -= L[NV * i + k] * L[NV * j + k];
+      L[NV * i + j] = sv * rd;
+    }
+  }
+  if (NV == 1) {
+    ddq.put(iv, x[0] * L[0]);
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {  // L y = x
+    double sv = x[i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) sv -= L[NV * i + k] * x[k];
+    x[i] = sv * L[NV * i + i];
+  }
+#pragma unroll
+  for (int i = NV - 1; i >= 0; --i) {  // L^T z = y
+    double sv = x[i];
+#pragma unroll
+    for (int k = i + 1; k < NV; ++k) sv -= L[NV * k + i] * x[k];
+    x[i] = sv * L[NV * i + i];
+  }
+#pragma unroll
+  for (int r = 0; r < NV; ++r) ddq.put(iv + r, x[r]);
+}
+
+// Multi-dof joints in the MIDDLE of a tree (spherical shoulders, nested free-flyers) are rare; their
+// backward visit is kept out of line so that its 6x6 temporaries do not set the register budget of
+// the 1-dof main path.  Arguments travel through private memory on purpose.
+template <int NV, class MatT>
+__device__ __noinline__ void aba_backward_multi(const KArgs* A, const JointConst* jc, const Op* op,
+                                                const GlobalStore* H, const double* R, const double* t,
+                                                const double* bias, const MatT* tauin, double tau0,
+                                                const MatT* ddq, double* Ia, double* of) {
+  double J[6 * NV];
+  jcols_multi<NV>(R, t, J);
+  aba_backward<NV>(*A, *jc, *op, *H, false, J, bias, *tauin, tau0, *ddq, Ia, of);
+}
+
 template <class MatT>
 DI void aba_backward_any(const KArgs& A, const JointConst& jc, const Op& op, const GlobalStore& H, bool root,
-                         const double* R, const double* t, const double* bias, const MatT& tauin,
+                         const double* R, const double* t, const double* bias, const MatT& tauin, double tau0,
                          const MatT& ddq, double* Ia, double* of) {
   if (op.nvj == 1) {
     double J[6];
     jcol_1dof(op, R, t, J);
-    aba_backward<1>(A, jc, op, H, root, J, bias, tauin, ddq, Ia, of);
-  } else if (op.nvj == 6) {
-    double J[36];
-    jcols_multi<6>(R, t, J);
-    aba_backward<6>(A, jc, op, H, root, J, bias, tauin, ddq, Ia, of);
+    if (root) aba_root_solve<1>(A, jc, op, J, tauin, tau0, ddq, Ia, of);
+    else aba_backward<1>(A, jc, op, H, false, J, bias, tauin, tau0, ddq, Ia, of);
+  } else if (root) {
+    if (op.nvj == 6) {
+      double J[36];
+      jcols_multi<6>(R, t, J);
+      aba_root_solve<6>(A, jc, op, J, tauin, tau0, ddq, Ia, of);
+    } else {
+      double J[18];
+      jcols_multi<3>(R, t, J);
+      aba_root_solve<3>(A, jc, op, J, tauin, tau0, ddq, Ia, of);
+    }
   } else {
-    double J[18];
-    jcols_multi<3>(R, t, J);
-    aba_backward<3>(A, jc, op, H, root, J, bias, tauin, ddq, Ia, of);
+    // private copies: only these escape to the out-of-line call
+    double cR[9], ct[3], cb[6], cIa[21], cof[6];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) cR[k] = R[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) ct[k] = t[k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { cb[k] = bias[k]; cof[k] = of[k]; }
+#pragma unroll
+    for (int k = 0; k < 21; ++k) cIa[k] = Ia[k];
+    const KArgs cA = A;
+    const JointConst cj = jc;
+    const Op cop = op;
+    const GlobalStore cH = H;
+    const MatT ctau = tauin, cddq = ddq;
+    if (op.nvj == 6) aba_backward_multi<6>(&cA, &cj, &cop, &cH, cR, ct, cb, &ctau, tau0, &cddq, cIa, cof);
+    else aba_backward_multi<3>(&cA, &cj, &cop, &cH, cR, ct, cb, &ctau, tau0, &cddq, cIa, cof);
+#pragma unroll
+    for (int k = 0; k < 21; ++k) Ia[k] = cIa[k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) of[k] = cof[k];
   }
 }
 
 struct AbaState {
-  double R[9], t[3], ov[6];  // state of the most recent forward visit
+  double R[9], t[3], ov[6];  // world placement / velocity of the joint the walk currently stands on
   double cIa[21], cof[6];    // carry registers child -> parent
 };
 DI void aba_state_init(AbaState& st) {
@@ -522,102 +648,64 @@ DI void aba_state_init(AbaState& st) {
   for (int k = 0; k < 21; ++k) st.cIa[k] = 0.0;
 }
 
-// one op of passes 1 + 2 (depth-first)
+// one op of passes 1 + 2 (depth-first).  Invariant: on entry of FWD(i) the state holds the
+// kinematics of parent(i); on entry of BWD(i) it holds those of i; on exit of a backward visit it
+// holds those of parent(i).
 template <class MatT, class Stack>
-DI void aba_step12(const KArgs& A, const Op op, const AbaLayout L, Stack& S, const GlobalStore& H,
+DI void aba_step12(const KArgs& A, const Op op, const Pre pre, const AbaLayout L, Stack& S, const GlobalStore& H,
                    const MatT& q, const MatT& vin, const MatT& tauin, const MatT& ddq, AbaState& st) {
   JointConst jc;
   load_joint(A.tab, op.joint, jc);
   const int fl = op.flags;
   const bool root = fl & F_PARENT_ROOT;
-  double Ia[21], of[6], bias[6];
+  double Ia[21], of[6], bias[6], Rl[9], tl[3], vJ[6], ovJ[6];
   double sn = 0.0, cs = 1.0;
+  joint_S_times(op, vin, pre.v0, vJ);
   if (!(fl & OP_BWD)) {
     // ---------------- forward visit (aba.hxx:102-139) ----------------
-    double Rp[9], tp[3], ovp[6];
-    if (fl & F_FROM_REGS) {
+    joint_liMi(jc, op, q, pre.q0, false, sn, cs, Rl, tl);
+    double Rp[9], tp[3];
 #pragma unroll
-      for (int k = 0; k < 9; ++k) Rp[k] = st.R[k];
+    for (int k = 0; k < 9; ++k) Rp[k] = st.R[k];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) tp[k] = st.t[k];
+    for (int k = 0; k < 3; ++k) tp[k] = st.t[k];
+    compose(root, Rp, tp, Rl, tl, st.R, st.t);  // :118-122
+    se3_act_motion(st.R, st.t, vJ, ovJ);        // :126
+    if (root) {
 #pragma unroll
-      for (int k = 0; k < 6; ++k) ovp[k] = st.ov[k];
-    } else if (!root) {
-      const int base = L.kb0 + op.bslot * 18;
-#pragma unroll
-      for (int k = 0; k < 9; ++k) Rp[k] = S.ld(base + k);
-#pragma unroll
-      for (int k = 0; k < 3; ++k) tp[k] = S.ld(base + 9 + k);
-#pragma unroll
-      for (int k = 0; k < 6; ++k) ovp[k] = S.ld(base + 12 + k);
+      for (int k = 0; k < 6; ++k) st.ov[k] = ovJ[k];
     } else {
 #pragma unroll
-      for (int k = 0; k < 9; ++k) Rp[k] = 0.0;
-#pragma unroll
-      for (int k = 0; k < 3; ++k) tp[k] = 0.0;
-#pragma unroll
-      for (int k = 0; k < 6; ++k) ovp[k] = 0.0;
+      for (int k = 0; k < 6; ++k) st.ov[k] += ovJ[k];  // :127-128
     }
-    aba_kin(jc, op, q, vin, root, false, sn, cs, Rp, tp, ovp, st.R, st.t, st.ov, bias);
-    // (s, c) of revolute joints go to the hand-off record for pass 3
+    // (s, c) go to the hand-off record for pass 3 ...
     {
       const int h = op.hand_off + hand_size(op.nvj) - 2;
       H.st(h, sn);
       H.st(h + 1, cs);
     }
     if (fl & F_PUSH_BRANCH) {
-      const int bs = op_own_bslot(fl);
-      const int kb = L.kb0 + bs * 18;
-#pragma unroll
-      for (int k = 0; k < 9; ++k) S.st(kb + k, st.R[k]);
-#pragma unroll
-      for (int k = 0; k < 3; ++k) S.st(kb + 9 + k, st.t[k]);
-#pragma unroll
-      for (int k = 0; k < 6; ++k) S.st(kb + 12 + k, st.ov[k]);
       // accumulator starts with the joint's own inertia and bias force (aba.hxx:134-138)
       aba_own_inertia(jc, st.R, st.t, st.ov, Ia, of);
-      const int ac = L.acc0 + bs * 27;
+      const int ac = L.acc0 + op_own_bslot(fl) * 27;
 #pragma unroll
       for (int k = 0; k < 21; ++k) S.st(ac + k, Ia[k]);
 #pragma unroll
       for (int k = 0; k < 6; ++k) S.st(ac + 21 + k, of[k]);
     }
     if (!(fl & F_LEAF)) {
-      const int base = L.kin0 + op.depth * 18;
-#pragma unroll
-      for (int k = 0; k < 9; ++k) S.st(base + k, st.R[k]);
-#pragma unroll
-      for (int k = 0; k < 3; ++k) S.st(base + 9 + k, st.t[k]);
-#pragma unroll
-      for (int k = 0; k < 6; ++k) S.st(base + 12 + k, st.ov[k]);
+      // ... and to the path stack for the backward visit
+      S.st(L.sc0 + 2 * op.depth, sn);
+      S.st(L.sc0 + 2 * op.depth + 1, cs);
       return;
     }
-    // leaf: backward arithmetic right away with (R, t, ov, bias) in registers
     aba_own_inertia(jc, st.R, st.t, st.ov, Ia, of);
-    aba_backward_any(A, jc, op, H, root, st.R, st.t, bias, tauin, ddq, Ia, of);
   } else {
     // ---------------- backward visit of a non-leaf joint (aba.hxx:153-193) ----------------
-    double Rb[9], tb[3], ovb[6];
-    const int base = L.kin0 + op.depth * 18;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) Rb[k] = S.ld(base + k);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) tb[k] = S.ld(base + 9 + k);
-#pragma unroll
-    for (int k = 0; k < 6; ++k) ovb[k] = S.ld(base + 12 + k);
-    double vJ[6], ovJ[6];
-    // bias = ov_parent x ov with ov_parent = ov - oMi.act(vJ) (aba.hxx:126-132)
-    joint_S_times(op, vin, vJ);
-    se3_act_motion(Rb, tb, vJ, ovJ);
-    if (root) {
-#pragma unroll
-      for (int k = 0; k < 6; ++k) bias[k] = 0.0;
-    } else {
-      double ovp[6];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) ovp[k] = ovb[k] - ovJ[k];
-      motion_cross(ovp, ovb, bias);
-    }
+    sn = S.ld(L.sc0 + 2 * op.depth);
+    cs = S.ld(L.sc0 + 2 * op.depth + 1);
+    joint_liMi(jc, op, q, pre.q0, true, sn, cs, Rl, tl);
+    se3_act_motion(st.R, st.t, vJ, ovJ);
     if (fl & F_MULTI) {
       const int ac = L.acc0 + op_own_bslot(fl) * 27;
 #pragma unroll
@@ -625,28 +713,53 @@ DI void aba_step12(const KArgs& A, const Op op, const AbaLayout L, Stack& S, con
 #pragma unroll
       for (int k = 0; k < 6; ++k) of[k] = S.ld(ac + 21 + k);
     } else {
-      aba_own_inertia(jc, Rb, tb, ovb, Ia, of);
+      aba_own_inertia(jc, st.R, st.t, st.ov, Ia, of);
 #pragma unroll
       for (int k = 0; k < 21; ++k) Ia[k] += st.cIa[k];  // aba.hxx:190-191 (single child)
 #pragma unroll
       for (int k = 0; k < 6; ++k) of[k] += st.cof[k];
     }
-    aba_backward_any(A, jc, op, H, root, Rb, tb, bias, tauin, ddq, Ia, of);
   }
+  // ---- backward arithmetic; bias = ov_parent x ov with ov_parent = ov - oMi.act(vJ) (:126-132) ----
+  double ovp[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) ovp[k] = root ? 0.0 : st.ov[k] - ovJ[k];
+  if (root) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) bias[k] = 0.0;
+  } else {
+    motion_cross(ovp, st.ov, bias);
+  }
+  aba_backward_any(A, jc, op, H, root, st.R, st.t, bias, tauin, pre.x0, ddq, Ia, of);
+  if (root) return;
   // ---- hand the articulated contribution to the parent (aba.hxx:190-191) ----
-  if (!root) {
-    if (fl & F_CARRY_REGS) {
+  if (fl & F_CARRY_REGS) {
 #pragma unroll
-      for (int k = 0; k < 21; ++k) st.cIa[k] = Ia[k];
+    for (int k = 0; k < 21; ++k) st.cIa[k] = Ia[k];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) st.cof[k] = of[k];
-    } else {
-      const int ac = L.acc0 + op.bslot * 27;  // parent's accumulator
+    for (int k = 0; k < 6; ++k) st.cof[k] = of[k];
+  } else {
+    const int ac = L.acc0 + op.bslot * 27;  // parent's accumulator
 #pragma unroll
-      for (int k = 0; k < 21; ++k) S.st(ac + k, S.ld(ac + k) + Ia[k]);
+    for (int k = 0; k < 21; ++k) S.st(ac + k, S.ld(ac + k) + Ia[k]);
 #pragma unroll
-      for (int k = 0; k < 6; ++k) S.st(ac + 21 + k, S.ld(ac + 21 + k) + of[k]);
-    }
+    for (int k = 0; k < 6; ++k) S.st(ac + 21 + k, S.ld(ac + 21 + k) + of[k]);
+  }
+  // ---- step back onto the parent: oMp = oMi * liMi^-1, ov_p = ov_i - oMi.act(vJ_i) ----
+  {
+    double Rn[9], Rt[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        Rn[3 * r + c] = st.R[3 * r] * Rl[3 * c] + st.R[3 * r + 1] * Rl[3 * c + 1] + st.R[3 * r + 2] * Rl[3 * c + 2];
+    rot_vec(Rn, tl, Rt);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) st.R[k] = Rn[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) st.t[k] -= Rt[k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) st.ov[k] = ovp[k];
   }
 }
 
@@ -662,9 +775,24 @@ DI void aba3_state_init(Aba3State& st) {
   for (int k = 0; k < 6; ++k) st.ov[k] = st.acc[k] = 0.0;
 }
 
+// pass-3 prefetch: joint velocity + the 1-dof hand-off record (UDinv 6, Dinv*u, s, c)
+struct Pre3 {
+  double q0, v0, h[9];
+};
+template <class MatT>
+DI Pre3 prefetch3(const Op& op, const GlobalStore& H, const MatT& q, const MatT& v) {
+  Pre3 p;
+  p.q0 = q.get(op.idx_q);
+  p.v0 = v.get(op.idx_v);
+  const int h = op.hand_off + (op.nvj == 1 ? 0 : hand_size(op.nvj) - 9);  // last 9 slots hold (.., s, c)
+#pragma unroll
+  for (int k = 0; k < 9; ++k) p.h[k] = H.ld(h + k);
+  return p;
+}
+
 // one op of pass 3 (aba.hxx:207-232), forward
 template <class MatT, class Stack>
-DI void aba_step3(const KArgs& A, const Op op, const AbaLayout L, Stack& S, const GlobalStore& H,
+DI void aba_step3(const KArgs& A, const Op op, const Pre3 pre, const AbaLayout L, Stack& S, const GlobalStore& H,
                   const MatT& q, const MatT& vin, const MatT& ddq, Aba3State& st) {
   JointConst jc;
   load_joint(A.tab, op.joint, jc);
@@ -687,7 +815,7 @@ DI void aba_step3(const KArgs& A, const Op op, const AbaLayout L, Stack& S, cons
 #pragma unroll
     for (int k = 0; k < 6; ++k) { ovp[k] = st.ov[k]; ap[k] = st.acc[k]; }
   } else {
-    const int base = L.k30 + op.bslot * 24;
+    const int base = L.acc0 + op.bslot * 27;
 #pragma unroll
     for (int k = 0; k < 9; ++k) Rp[k] = S.ld(base + k);
 #pragma unroll
@@ -695,24 +823,30 @@ DI void aba_step3(const KArgs& A, const Op op, const AbaLayout L, Stack& S, cons
 #pragma unroll
     for (int k = 0; k < 6; ++k) { ovp[k] = S.ld(base + 12 + k); ap[k] = S.ld(base + 18 + k); }
   }
-  const int h = op.hand_off;
-  double sn = H.ld(h + hand_size(op.nvj) - 2);
-  double cs = H.ld(h + hand_size(op.nvj) - 1);
-  double bias[6];
-  aba_kin(jc, op, q, vin, root, true, sn, cs, Rp, tp, ovp, st.R, st.t, st.ov, bias);
+  double sn = pre.h[7], cs = pre.h[8];
+  double Rl[9], tl[3], vJ[6], ovJ[6], bias[6];
+  joint_liMi(jc, op, q, pre.q0, true, sn, cs, Rl, tl);
+  compose(root, Rp, tp, Rl, tl, st.R, st.t);
+  joint_S_times(op, vin, pre.v0, vJ);
+  se3_act_motion(st.R, st.t, vJ, ovJ);
+  if (root) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { st.ov[k] = ovJ[k]; bias[k] = 0.0; }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) st.ov[k] = ovJ[k] + ovp[k];
+    motion_cross(ovp, st.ov, bias);
+  }
 #pragma unroll
   for (int k = 0; k < 6; ++k) st.acc[k] = ap[k] + bias[k];  // :223 (oa_gf[i] += oa_gf[parent])
-  const int iv = op.idx_v;
+  const int iv = op.idx_v, h = op.hand_off;
   const bool leaf = fl & F_LEAF;
   if (op.nvj == 1) {
     double dd;
     if (root) {
       dd = ddq.get(iv);  // written by the backward visit of this lane
     } else {
-      double UD[6];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) UD[k] = H.ld(h + k);
-      dd = H.ld(h + 6) - dot6(UD, st.acc);  // :224-226
+      dd = pre.h[6] - dot6(pre.h, st.acc);  // :224-226
       ddq.put(iv, dd);
     }
     if (!leaf) {
@@ -767,7 +901,7 @@ DI void aba_step3(const KArgs& A, const Op op, const AbaLayout L, Stack& S, cons
       for (int k = 0; k < 6; ++k) st.acc[k] += J[6 * c + k] * dd[c];
   }
   if (fl & F_PUSH_BRANCH) {
-    const int base = L.k30 + op_own_bslot(fl) * 24;
+    const int base = L.acc0 + op_own_bslot(fl) * 27;
 #pragma unroll
     for (int k = 0; k < 9; ++k) S.st(base + k, st.R[k]);
 #pragma unroll
@@ -782,8 +916,9 @@ __global__ __launch_bounds__(WAVE) void aba_kernel(const KArgs A) {
   const int lane = threadIdx.x;
   double* const wbase = A.ws + (int64_t)blockIdx.x * A.ws_stride;
   const AbaLayout L = aba_layout(A.maxdepth, A.maxbranch);
-  GlobalStore S(wbase, (unsigned)lane);
-  const GlobalStore H(wbase + (int64_t)L.end * WAVE, (unsigned)lane);
+  const int gstack = L.end > A.lds_cap ? L.end - A.lds_cap : 0;  // stack slots that overflow LDS
+  HybridStore S(brbd_smem, A.lds_cap, wbase, (unsigned)lane);
+  const GlobalStore H(wbase + (int64_t)gstack * WAVE, (unsigned)lane);
   for (int64_t tile = blockIdx.x; tile < A.ntiles; tile += gridDim.x) {
     const Mat<LAYOUT> q(const_cast<double*>(A.q), A.ldq, tile, A.B, lane);
     const Mat<LAYOUT> vin(const_cast<double*>(A.v), A.ldv, tile, A.B, lane);
@@ -791,10 +926,30 @@ __global__ __launch_bounds__(WAVE) void aba_kernel(const KArgs A) {
     const Mat<LAYOUT> ddq(A.out, A.ldout, tile, A.B, lane);
     AbaState st;
     aba_state_init(st);
-    for (int s = 0; s < A.nops; ++s) aba_step12(A, load_op(A.prog, s), L, S, H, q, vin, tauin, ddq, st);
+    {
+      Op op = load_op(A.prog, 0);
+      Pre pre = prefetch(op, q, vin, tauin);
+      for (int s = 0; s < A.nops; ++s) {
+        const Op nxt = load_op(A.prog, s + 1 < A.nops ? s + 1 : s);
+        const Pre pn = prefetch(nxt, q, vin, tauin);
+        aba_step12(A, op, pre, L, S, H, q, vin, tauin, ddq, st);
+        op = nxt;
+        pre = pn;
+      }
+    }
     Aba3State st3;
     aba3_state_init(st3);
-    for (int s = 0; s < A.nops3; ++s) aba_step3(A, load_op(A.prog3, s), L, S, H, q, vin, ddq, st3);
+    {
+      Op op = load_op(A.prog3, 0);
+      Pre3 pre = prefetch3(op, H, q, vin);
+      for (int s = 0; s < A.nops3; ++s) {
+        const Op nxt = load_op(A.prog3, s + 1 < A.nops3 ? s + 1 : s);
+        const Pre3 pn = prefetch3(nxt, H, q, vin);
+        aba_step3(A, op, pre, L, S, H, q, vin, ddq, st3);
+        op = nxt;
+        pre = pn;
+      }
+    }
   }
 }
 
@@ -812,7 +967,7 @@ DI void fkjac_step(const KArgs& A, const Op op, Stack& S, const MatT& q, const M
   const int fl = op.flags;
   const bool root = fl & F_PARENT_ROOT;
   double Rl[9], tl[3], sn, cs;
-  joint_liMi(jc, op, q, false, sn, cs, Rl, tl);
+  joint_liMi(jc, op, q, q.get(op.idx_q), false, sn, cs, Rl, tl);
   if (root) {
 #pragma unroll
     for (int k = 0; k < 9; ++k) st.R[k] = Rl[k];

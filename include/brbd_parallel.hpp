@@ -1,0 +1,168 @@
+// brbd_parallel.hpp -- header-only C++ host mirror of Pinocchio's parallel entry points on top of
+// the C ABI (include/brbd.h).  Same names, argument order and error behaviour as
+//   pinocchio::rneaInParallel  (include/pinocchio/algorithm/parallel/rnea.hpp:31-83)
+//   pinocchio::abaInParallel   (include/pinocchio/algorithm/parallel/aba.hpp:32-84)
+//   pinocchio::ModelPoolTpl    (include/pinocchio/multibody/pool/model.hpp:19-165)
+// so that a caller switches by changing the namespace.  Matrices are any column-major type with
+// rows(), cols(), data() and outerStride() (Eigen::MatrixXd, Eigen::Map, Eigen::Ref ...): one
+// instance per contiguous column = BRBD_INSTANCE_MAJOR with ld = outerStride(), host memory.
+//
+// When Pinocchio's headers are visible, brbd::make_desc(pinocchio::Model) flattens a real model
+// (fields of SURVEY 8a row a13; joint kind from shortname(), e.g. joint-revolute.hpp:848-851).
+#pragma once
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "brbd.h"
+
+namespace brbd {
+
+// Owning, plain-table description of a model (what brbd_model_desc points into).
+struct ModelDesc {
+  int njoints = 1, nq = 0, nv = 0;
+  std::vector<int32_t> parents{0}, jtype{0}, idx_q{0}, idx_v{0};
+  std::vector<double> placement = std::vector<double>(12, 0.0), inertia = std::vector<double>(10, 0.0),
+                      axis = std::vector<double>(3, 0.0), armature;
+  double gravity[3] = {0.0, 0.0, -9.81};
+
+  brbd_model_desc view() const {
+    brbd_model_desc d;
+    d.njoints = njoints; d.nq = nq; d.nv = nv;
+    d.parents = parents.data(); d.jtype = jtype.data(); d.idx_q = idx_q.data(); d.idx_v = idx_v.data();
+    d.placement = placement.data(); d.inertia = inertia.data(); d.axis = axis.data();
+    d.armature = armature.empty() ? nullptr : armature.data();
+    for (int k = 0; k < 3; ++k) d.gravity[k] = gravity[k];
+    return d;
+  }
+};
+
+inline void throw_status(int rc) {
+  if (rc == BRBD_OK) return;
+  const std::string msg = brbd_last_error();
+  if (rc == BRBD_ERR_INVALID_ARGUMENT || rc == BRBD_ERR_UNSUPPORTED) throw std::invalid_argument(msg);
+  throw std::runtime_error(msg);
+}
+
+// Counterpart of ModelPoolTpl: `size` replicas in the reference, one flattened BatchModel per GPU
+// here; size() only feeds the reference's argument checks.
+class ModelPool {
+ public:
+  explicit ModelPool(const ModelDesc& model, size_t pool_size = 1, int device = 0)
+      : desc_(model), size_(pool_size), device_(device) {}
+  ~ModelPool() { release(); }
+  ModelPool(const ModelPool&) = delete;
+  ModelPool& operator=(const ModelPool&) = delete;
+
+  size_t size() const { return size_; }
+  void resize(size_t n) { size_ = n; }
+  const ModelDesc& getModel(size_t index = 0) const {
+    if (index >= (size_ ? size_ : 1)) throw std::invalid_argument("Index greater than the size of the model vector.");
+    return desc_;
+  }
+  void update(const ModelDesc& model) {  // pool/model.hpp:68-73
+    desc_ = model;
+    release();
+  }
+  brbd_model* handle() {
+    if (!h_) {
+      const brbd_model_desc d = desc_.view();
+      throw_status(brbd_model_create(&d, device_, &h_));
+    }
+    return h_;
+  }
+  void release() {
+    if (h_) brbd_model_destroy(h_);
+    h_ = nullptr;
+  }
+
+ private:
+  ModelDesc desc_;
+  size_t size_;
+  int device_;
+  brbd_model* h_ = nullptr;
+};
+
+namespace detail {
+inline void check(bool ok, const char* msg) {
+  if (!ok) throw std::invalid_argument(msg);  // PINOCCHIO_CHECK_INPUT_ARGUMENT, macros.hpp:201-215
+}
+}  // namespace detail
+
+// tau = rnea(q, v, a) column by column; `tau` is the LAST argument and is written through a const
+// reference exactly like the reference does with const_cast_derived() (parallel/rnea.hpp:59).
+template <class ConfigPool, class Tangent1, class Tangent2, class Tangent3>
+void rneaInParallel(const size_t num_threads, ModelPool& pool, const ConfigPool& q, const Tangent1& v,
+                    const Tangent2& a, const Tangent3& tau) {
+  detail::check(pool.size() > 0, "The pool should have at least one element");  // rnea.hpp:53
+  detail::check(num_threads <= pool.size(), "The pool is too small");            // rnea.hpp:54
+  const ModelDesc& m = pool.getModel(0);
+  detail::check(q.rows() == m.nq, "q.rows() != model.nq");                       // rnea.hpp:61-68
+  detail::check(v.rows() == m.nv && a.rows() == m.nv && tau.rows() == m.nv, "rows != model.nv");
+  detail::check(q.cols() == v.cols() && q.cols() == a.cols() && q.cols() == tau.cols(), "column mismatch");
+  throw_status(brbd_rnea(pool.handle(), (int64_t)q.cols(), q.data(), (int64_t)q.outerStride(), v.data(),
+                         (int64_t)v.outerStride(), a.data(), (int64_t)a.outerStride(),
+                         const_cast<double*>(tau.data()), (int64_t)tau.outerStride(), BRBD_INSTANCE_MAJOR,
+                         BRBD_HOST, nullptr));
+}
+
+// a = aba(q, v, tau, Convention::WORLD) column by column (parallel/aba.hpp:40-84).
+template <class ConfigPool, class Tangent1, class Tangent2, class Tangent3>
+void abaInParallel(const size_t num_threads, ModelPool& pool, const ConfigPool& q, const Tangent1& v,
+                   const Tangent2& tau, const Tangent3& a) {
+  detail::check(pool.size() > 0, "The pool should have at least one element");
+  detail::check(num_threads <= pool.size(), "The pool is too small");
+  const ModelDesc& m = pool.getModel(0);
+  detail::check(q.rows() == m.nq, "q.rows() != model.nq");
+  detail::check(v.rows() == m.nv && a.rows() == m.nv && tau.rows() == m.nv, "rows != model.nv");
+  detail::check(q.cols() == v.cols() && q.cols() == a.cols() && q.cols() == tau.cols(), "column mismatch");
+  throw_status(brbd_aba(pool.handle(), (int64_t)q.cols(), q.data(), (int64_t)q.outerStride(), v.data(),
+                        (int64_t)v.outerStride(), tau.data(), (int64_t)tau.outerStride(),
+                        const_cast<double*>(a.data()), (int64_t)a.outerStride(), BRBD_INSTANCE_MAJOR,
+                        BRBD_HOST, nullptr));
+}
+
+}  // namespace brbd
+
+// ------------------------------------------------------------------------------------------------
+// Optional adapter, compiled only where Pinocchio (and therefore Eigen/Boost) is installed.
+#if defined(__has_include)
+#if __has_include(<pinocchio/multibody/model.hpp>)
+#include <pinocchio/multibody/model.hpp>
+namespace brbd {
+inline int joint_type_from_shortname(const std::string& s) {
+  static const char* names[] = {"JointModelRX", "JointModelRY", "JointModelRZ", "JointModelPX", "JointModelPY",
+                                "JointModelPZ", "JointModelFreeFlyer", "JointModelSpherical",
+                                "JointModelRevoluteUnaligned", "JointModelPrismaticUnaligned", "JointModelRUBX",
+                                "JointModelRUBY", "JointModelRUBZ"};
+  for (int k = 0; k < BRBD_JOINT_TYPE_COUNT; ++k)
+    if (s == names[k]) return k;
+  throw std::invalid_argument("joint kind " + s + " is not supported by the brbd engine");
+}
+inline ModelDesc make_desc(const pinocchio::Model& model) {
+  ModelDesc d;
+  const int n = model.njoints;
+  d.njoints = n; d.nq = model.nq; d.nv = model.nv;
+  d.parents.assign(n, 0); d.jtype.assign(n, 0); d.idx_q.assign(n, 0); d.idx_v.assign(n, 0);
+  d.placement.assign(12 * (size_t)n, 0.0); d.inertia.assign(10 * (size_t)n, 0.0); d.axis.assign(3 * (size_t)n, 0.0);
+  d.armature.assign(model.armature.data(), model.armature.data() + model.nv);
+  for (int k = 0; k < 3; ++k) d.gravity[k] = model.gravity.linear()[k];
+  for (int i = 1; i < n; ++i) {
+    d.parents[i] = (int32_t)model.parents[(size_t)i];
+    d.jtype[i] = joint_type_from_shortname(model.joints[(size_t)i].shortname());
+    d.idx_q[i] = model.idx_qs[(size_t)i];
+    d.idx_v[i] = model.idx_vs[(size_t)i];
+    const auto& P = model.jointPlacements[(size_t)i];
+    std::memcpy(&d.placement[12 * (size_t)i], P.rotation().data(), 9 * sizeof(double));  // column-major
+    std::memcpy(&d.placement[12 * (size_t)i + 9], P.translation().data(), 3 * sizeof(double));
+    const auto& Y = model.inertias[(size_t)i];
+    d.inertia[10 * (size_t)i] = Y.mass();
+    std::memcpy(&d.inertia[10 * (size_t)i + 1], Y.lever().data(), 3 * sizeof(double));
+    std::memcpy(&d.inertia[10 * (size_t)i + 4], Y.inertia().data().data(), 6 * sizeof(double));
+  }
+  return d;
+}
+}  // namespace brbd
+#endif
+#endif

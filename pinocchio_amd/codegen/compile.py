@@ -1,0 +1,126 @@
+"""Driver of the model compiler: model -> kernel bodies (.inc), packed constant table, signature.
+
+``build_kernel`` runs an algorithm's generator twice (dry pass to learn the lifetimes of the
+parked values, storage plan, final pass) and returns the emitted body with the metadata the host
+needs: the gather list of the packed constant table and the sizes of the LDS / global park areas.
+
+``cpu_library`` wraps the same bodies in a scalar C function and compiles it with gcc: that is
+how tests/test_codegen_cpu.py checks the generator against the oracle without a GPU.
+"""
+from __future__ import annotations
+
+import ctypes
+import hashlib
+import os
+import subprocess
+import tempfile
+from typing import Dict, Optional
+
+import numpy as np
+
+from .. import model as M
+from . import aba, fkjac, joints, rnea
+from .emit import Emitter, plan_storage
+
+ALGOS = {"rnea": rnea.generate, "aba": aba.generate, "fkjac": fkjac.generate}
+
+# storage budgets (doubles per lane) of the park planner, per algorithm: (registers, LDS)
+# LDS: 160 KiB per CU, 4 resident waves of 64 lanes at one wave per SIMD -> 80 doubles per lane
+BUDGETS = {"rnea": (72, 80), "aba": (96, 80), "fkjac": (48, 80)}
+
+
+class Kernel:
+    def __init__(self, algo, text, const_list, lds, glb, stats, nvisits):
+        self.algo, self.text, self.const_list = algo, text, const_list
+        self.lds, self.glb, self.stats, self.nvisits = lds, glb, stats, nvisits
+
+
+def build_kernel(mv: joints.ModelView, algo: str, reg_budget: Optional[int] = None,
+                 lds_budget: Optional[int] = None) -> Kernel:
+    gen = ALGOS[algo]
+    rb, lb = BUDGETS[algo]
+    rb = rb if reg_budget is None else reg_budget
+    lb = lb if lds_budget is None else lds_budget
+    dry = gen(mv, Emitter())
+    plan, lds, glb = plan_storage(dry.parks, rb, lb)
+    e = gen(mv, Emitter(plan))
+    return Kernel(algo, e.text(), list(e.const_list), lds, glb, dict(e.stats), len(e.visits))
+
+
+def pack_constants(mv: joints.ModelView, const_list) -> np.ndarray:
+    return np.array([mv.value(ident) for ident in const_list] + [0.0], dtype=np.float64)
+
+
+_CPU_SHELL = r"""
+#define _GNU_SOURCE
+#include <math.h>
+#define CT(k) ct[k]
+#define IN_Q(k) q[k]
+#define IN_V(k) v[k]
+#define IN_X(k) x[k]
+#define OUT(k, val) out[k] = (val)
+#define OUT2(k, val) out2[k] = (val)
+#define OUT3(k, val) out3[k] = (val)
+#define SINCOS(a, s, c) sincos(a, &s, &c)
+#define RSQRT(a) (1.0 / sqrt(a))
+#define RCP(a) (1.0 / (a))
+#define FMA(a, b, c) fma(a, b, c)
+#define PK_LDS_ST2(p, a, b) do { lds[2 * (p)] = (a); lds[2 * (p) + 1] = (b); } while (0)
+#define PK_LDS_LD2(p, a, b) do { a = lds[2 * (p)]; b = lds[2 * (p) + 1]; } while (0)
+#define PK_GLB_ST2(p, a, b) do { glb[2 * (p)] = (a); glb[2 * (p) + 1] = (b); } while (0)
+#define PK_GLB_LD2(p, a, b) do { a = glb[2 * (p)]; b = glb[2 * (p) + 1]; } while (0)
+#define VISIT_END() do { } while (0)
+static void one(const double* ct, const double* q, const double* v, const double* x, double* out,
+                double* out2, double* out3, double* lds, double* glb) {
+  (void)ct; (void)q; (void)v; (void)x; (void)out; (void)out2; (void)out3; (void)lds; (void)glb;
+#include "BODY"
+}
+void spec_batch(const double* ct, long B, const double* q, long ldq, const double* v, long ldv,
+                const double* x, long ldx, double* out, long ldo, double* out2, long ldo2, double* out3,
+                long ldo3) {
+  double lds[LDS_N + 2], glb[GLB_N + 2];
+  for (long b = 0; b < B; ++b)
+    one(ct, q + b * ldq, v ? v + b * ldv : 0, x ? x + b * ldx : 0, out + b * ldo, out2 ? out2 + b * ldo2 : 0,
+        out3 ? out3 + b * ldo3 : 0, lds, glb);
+}
+"""
+
+
+class CpuKernel:
+    """The generated body compiled for the host (checker of the generator, never a product path)."""
+
+    def __init__(self, mv: joints.ModelView, algo: str, **kw):
+        self.mv, self.kernel = mv, build_kernel(mv, algo, **kw)
+        self.ct = pack_constants(mv, self.kernel.const_list)
+        self.dir = tempfile.mkdtemp(prefix="brbd_cg_")
+        body = os.path.join(self.dir, "body.inc")
+        with open(body, "w") as f:
+            f.write(self.kernel.text)
+        src = os.path.join(self.dir, "shell.c")
+        with open(src, "w") as f:
+            f.write(_CPU_SHELL.replace("BODY", body).replace("LDS_N", str(self.kernel.lds)).replace(
+                "GLB_N", str(self.kernel.glb)))
+        so = os.path.join(self.dir, "spec.so")
+        # -ffp-contract=off: only the FMAs the generator asked for
+        subprocess.check_call(["gcc", "-O1", "-ffp-contract=off", "-shared", "-fPIC", "-o", so, src, "-lm"])
+        self.lib = ctypes.CDLL(so)
+        dp, l = ctypes.POINTER(ctypes.c_double), ctypes.c_long
+        self.lib.spec_batch.argtypes = [dp, l, dp, l, dp, l, dp, l, dp, l, dp, l, dp, l]
+
+    def run(self, q, v=None, x=None, out_rows=(0, 0, 0)):
+        def P(a):
+            return None if a is None else a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+        q = np.asfortranarray(q, dtype=np.float64)
+        B = q.shape[1]
+        v = None if v is None else np.asfortranarray(v, dtype=np.float64)
+        x = None if x is None else np.asfortranarray(x, dtype=np.float64)
+        outs = [np.zeros((r, B), order="F") if r else None for r in out_rows]
+        self.lib.spec_batch(P(self.ct), B, P(q), q.shape[0], P(v), 0 if v is None else v.shape[0], P(x),
+                            0 if x is None else x.shape[0], P(outs[0]), out_rows[0], P(outs[1]), out_rows[1],
+                            P(outs[2]), out_rows[2])
+        return outs
+
+
+def signature_hash(sig: str) -> str:
+    return hashlib.sha1(sig.encode()).hexdigest()[:16]

@@ -168,16 +168,17 @@ int brbd_transpose_to_batch_major(int device, int64_t dof, int64_t B, const doub
 int brbd_transpose_to_instance_major(int device, int64_t dof, int64_t B, const double* src,
                                      int64_t ld_src, double* dst, int64_t ld_dst, void* stream);
 
-/* Topology-specialised kernels (EXPERIMENTAL, off by default).  Topologies registered at build
- * time (tools/gen_static_models.py -> pinocchio_amd/csrc/brbd_static_models.inc) also get
- * unrolled, register-resident instantiations of the same step functions.  They are selected
- * only when the model's depth-first program matches a registered one exactly AND the caller
- * opts in (brbd_model_use_static(m, 1) or BRBD_ENABLE_STATIC=1): on ROCm 7.2 hipcc's register
- * allocation of the unrolled stream is worse than the table-driven kernels.
- * brbd_model_static_topology returns the matched topology name ("" = none).
- * No reference counterpart. */
-const char* brbd_model_static_topology(const brbd_model* m);
-int brbd_model_use_static(brbd_model* m, int enabled);
+/* Model-compiled kernels.  For models registered at build time (pinocchio_amd/codegen/build.py)
+ * the library also holds straight-line kernels generated for that very model: the recursion
+ * unrolled over its tree with every structural zero of its constants folded away ("<name>_p"),
+ * or with all geometric / inertial constants generic ("<name>_d": any model with the same tree and
+ * joint kinds).  brbd_model_create selects them when the model's signature matches; every other
+ * model runs on the table-driven kernels.  Both produce the results of the same recursions.
+ * brbd_model_compiled_kernels returns the matched entry's name ("" = table-driven);
+ * brbd_model_use_compiled(m, 0) forces the table-driven kernels (BRBD_DISABLE_COMPILED=1 does so
+ * for every model).  No reference counterpart (closest: the CppADCodeGen path, out of scope). */
+const char* brbd_model_compiled_kernels(const brbd_model* m);
+int brbd_model_use_compiled(brbd_model* m, int enabled);
 
 /* Kernel timing for the roofline (bench.py): with timing enabled every kernel launch of the
  * engine is bracketed by hipEvents recorded on the launch stream.  brbd_kernel_time() waits for

@@ -34,7 +34,7 @@ SYMBOLS = (
     "brbd_model_create", "brbd_model_destroy", "brbd_model_dims", "brbd_workspace_bytes",
     "brbd_rnea", "brbd_aba", "brbd_fk_jacobians", "brbd_rnea_derivatives",
     "brbd_transpose_to_batch_major", "brbd_transpose_to_instance_major",
-    "brbd_set_timing", "brbd_kernel_time", "brbd_model_static_topology", "brbd_model_use_static",
+    "brbd_set_timing", "brbd_kernel_time", "brbd_model_compiled_kernels", "brbd_model_use_compiled",
 )
 
 
@@ -109,10 +109,10 @@ def lib():
     L.brbd_transpose_to_batch_major.argtypes = [ci, i64, i64, vp, i64, vp, i64, vp]
     L.brbd_transpose_to_instance_major.restype = ci
     L.brbd_transpose_to_instance_major.argtypes = [ci, i64, i64, vp, i64, vp, i64, vp]
-    L.brbd_model_static_topology.restype = ctypes.c_char_p
-    L.brbd_model_static_topology.argtypes = [vp]
-    L.brbd_model_use_static.restype = ci
-    L.brbd_model_use_static.argtypes = [vp, ci]
+    L.brbd_model_compiled_kernels.restype = ctypes.c_char_p
+    L.brbd_model_compiled_kernels.argtypes = [vp]
+    L.brbd_model_use_compiled.restype = ci
+    L.brbd_model_use_compiled.argtypes = [vp, ci]
     L.brbd_set_timing.restype = ci
     L.brbd_set_timing.argtypes = [vp, ci]
     L.brbd_kernel_time.restype = ci
@@ -165,11 +165,11 @@ class DeviceModel:
     def workspace_bytes(self, algo: int, B: int) -> int:
         return int(lib().brbd_workspace_bytes(self.handle, algo, B))
 
-    def static_topology(self) -> str:
-        return lib().brbd_model_static_topology(self.handle).decode()
+    def compiled_kernels(self) -> str:
+        return lib().brbd_model_compiled_kernels(self.handle).decode()
 
-    def use_static(self, on: bool):
-        check(lib().brbd_model_use_static(self.handle, 1 if on else 0))
+    def use_compiled(self, on: bool):
+        check(lib().brbd_model_use_compiled(self.handle, 1 if on else 0))
 
     def set_timing(self, on: bool):
         check(lib().brbd_set_timing(self.handle, 1 if on else 0))

@@ -18,7 +18,8 @@
 #include "brbd_flatten.hpp"
 #include "brbd_kernels.hpp"
 #include "brbd_deriv.hpp"
-#include "brbd_static.hpp"
+#include "brbd_spec.hpp"
+#include "gen/registry.inc"
 
 using namespace brbd;
 
@@ -59,9 +60,11 @@ struct brbd_model {
   size_t stage_doubles = 0;
   // per-algorithm launch geometry (waves resident on the device)
   int max_waves[4] = {0, 0, 0, 0};
-  int max_waves_static[4] = {0, 0, 0, 0};
-  const StaticEntry* stat = nullptr;  // unrolled kernels for this topology, if registered
-  bool use_static = false;  // opt-in: BRBD_ENABLE_STATIC=1 or brbd_model_use_static(m, 1)
+  int max_waves_spec[4] = {0, 0, 0, 0};
+  // model-compiled kernels (brbd_spec.hpp), when the model's signature is registered
+  const SpecEntry* spec = nullptr;
+  double* d_ct[3] = {nullptr, nullptr, nullptr};  // packed constant table per algorithm
+  bool use_spec = true;  // BRBD_DISABLE_COMPILED=1 or brbd_model_use_compiled(m, 0): table-driven kernels
   bool use_lds = true;
   bool timing = false;
   std::vector<TimedLaunch> timed[4];
@@ -69,6 +72,52 @@ struct brbd_model {
 };
 
 namespace {
+
+// Signature of a model as pinocchio_amd/codegen/joints.py: ModelView.signature() builds it:
+// tree, joint kinds, and per constant one of 0 / 1 / m(-1) / g(eneric); `dense`: geometry and
+// inertias all generic (armature and gravity keep their pattern).
+double model_constant(const FlatModel& F, int joint, int field, int index) {
+  const JointConst& jc = F.tab[joint];
+  switch (field) {
+    case SF_R: return jc.R[index];
+    case SF_T: return jc.t[index];
+    case SF_M: return jc.m;
+    case SF_C: return jc.c[index];
+    case SF_I: return jc.I[index];
+    case SF_ARM: return jc.arm[index - jc.idx_v];
+    case SF_AXIS: return jc.axis[index];
+    default: return F.gravity[index];
+  }
+}
+std::string model_signature(const FlatModel& F, bool dense) {
+  std::string s = "n" + std::to_string(F.njoints) + ";p";
+  for (int i = 1; i < F.njoints; ++i) s += (i > 1 ? "," : "") + std::to_string(F.tab[i].parent);
+  s += ";j";
+  for (int i = 1; i < F.njoints; ++i) s += (i > 1 ? "," : "") + std::to_string(F.tab[i].jtype);
+  s += ";";
+  auto put = [&](double x, bool keep) {
+    char c = x == 0.0 ? '0' : (x == 1.0 ? '1' : (x == -1.0 ? 'm' : 'g'));
+    s += (dense && !keep) ? 'g' : c;
+  };
+  for (int k = 0; k < 3; ++k) put(F.gravity[k], true);
+  for (int i = 1; i < F.njoints; ++i) {
+    const JointConst& jc = F.tab[i];
+    for (int k = 0; k < 9; ++k) put(jc.R[k], false);
+    for (int k = 0; k < 3; ++k) put(jc.t[k], false);
+    put(jc.m, false);
+    for (int k = 0; k < 3; ++k) put(jc.c[k], false);
+    for (int k = 0; k < 6; ++k) put(jc.I[k], false);
+    for (int k = 0; k < 3; ++k) put(jc.axis[k], false);
+    for (int k = 0; k < jc.nvj; ++k) put(jc.arm[k], true);
+  }
+  return s;
+}
+std::vector<double> pack_constants(const FlatModel& F, const SpecKernel& k) {
+  std::vector<double> ct((size_t)k.nconst + 16, 0.0);  // padded: merged s_loads may read past the end
+  for (int c = 0; c < k.nconst; ++c)
+    ct[c] = model_constant(F, k.gather[3 * c], k.gather[3 * c + 1], k.gather[3 * c + 2]);
+  return ct;
+}
 
 int ensure_ws(brbd_model* m, size_t doubles) {
   if (doubles <= m->ws_doubles) return BRBD_OK;
@@ -177,18 +226,31 @@ int launch_algo(brbd_model* m, int algo, KArgs& A, int layout, hipStream_t strea
     case BRBD_ALGO_FK_JAC: per_lane = F.ws_fkjac(); break;
     default: return fail(BRBD_ERR_INVALID_ARGUMENT, "unknown algorithm");
   }
-  const bool stat = m->stat && m->use_static && layout == BRBD_BATCH_MAJOR;
-  KernelFn sfn = nullptr;
-  if (stat)
-    sfn = algo == BRBD_ALGO_RNEA ? m->stat->rnea : (algo == BRBD_ALGO_ABA ? m->stat->aba : m->stat->fkjac);
-  int& mw = stat ? m->max_waves_static[algo] : m->max_waves[algo];
+  // model-compiled kernel?  (BATCH_MAJOR addresses elements with 32-bit byte offsets)
+  const SpecKernel* sk = (m->spec && m->use_spec) ? &m->spec->algo[algo] : nullptr;
+  int variant = 0;
+  if (sk) {
+    if (algo == BRBD_ALGO_FK_JAC) variant = (A.out ? 1 : 0) | (A.out2 ? 2 : 0);
+    else variant = 0;
+    auto fits = [&](int64_t ld, int64_t dof) { return (double)ld * (double)dof * 8.0 < 4294967296.0; };
+    if (layout == BRBD_BATCH_MAJOR) {
+      bool ok = fits(A.ldq, F.nq);
+      if (algo != BRBD_ALGO_FK_JAC) ok = ok && fits(A.ldv, F.nv) && fits(A.lda, F.nv) && fits(A.ldout, F.nv);
+      else ok = ok && (!A.out || fits(A.ldout, 6 * (int64_t)F.nv)) && (!A.out2 || fits(A.ldout2, 12 * (int64_t)F.njoints));
+      if (!ok) sk = nullptr;
+    }
+    if (sk && !sk->fn[layout][variant]) sk = nullptr;
+  }
+  const bool stat = sk != nullptr;
+  SpecFn sfn = stat ? sk->fn[layout][variant] : nullptr;
+  int& mw = stat ? m->max_waves_spec[algo] : m->max_waves[algo];
   if (mw == 0) {
     int w = 0;
     if (stat) w = resident_waves(m, sfn, WAVE);
     else if (algo == BRBD_ALGO_RNEA) w = resident_waves(m, rnea_kernel<1>, WAVE);
     else if (algo == BRBD_ALGO_ABA) w = resident_waves(m, aba_kernel<1>, WAVE);
     else w = resident_waves(m, fkjac_kernel<1>, WAVE);
-    mw = w;  // VGPR-limited resident waves on the whole device
+    mw = w;  // register/LDS-limited resident waves on the whole device
   }
   // LDS part of the live-state stack (generic RNEA / ABA): as many slots as fit without lowering
   // the number of waves per CU below what this launch can use.
@@ -211,8 +273,8 @@ int launch_algo(brbd_model* m, int algo, KArgs& A, int layout, hipStream_t strea
     per_lane = (stack - lds_cap) + (algo == BRBD_ALGO_ABA ? F.hand_total : 0);
     if (per_lane < 1) per_lane = 1;
   } else if (stat) {
-    // the unrolled kernels keep the path state in registers: only ABA's hand-off records spill
-    per_lane = algo == BRBD_ALGO_ABA ? F.hand_total : 1;
+    per_lane = sk->glb_doubles > 0 ? sk->glb_doubles : 1;  // the storage plan's global park area
+    A.ctab = m->d_ct[algo];
   }
   A.lds_cap = lds_cap;
   int64_t grid = A.ntiles < resident ? A.ntiles : resident;
@@ -288,21 +350,8 @@ int brbd_model_create(const brbd_model_desc* desc, int device, brbd_model** out)
   }
   m->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   {
-    // select the unrolled kernels iff a registered topology has exactly this program
-    int cnt = 0;
-    const StaticEntry* reg = static_registry(&cnt);
-    for (int k = 0; k < cnt; ++k) {
-      const StaticEntry& e = reg[k];
-      if (e.njoints != F.njoints || e.nq != F.nq || e.nv != F.nv || e.nops != (int)F.prog.size() ||
-          e.nops3 != (int)F.prog3.size() || e.hand_total != F.hand_total)
-        continue;
-      if (std::memcmp(e.prog, F.prog.data(), sizeof(Op) * F.prog.size()) != 0) continue;
-      if (std::memcmp(e.prog3, F.prog3.data(), sizeof(Op) * F.prog3.size()) != 0) continue;
-      m->stat = &e;
-      break;
-    }
-    const char* env = getenv("BRBD_ENABLE_STATIC");
-    if (env && env[0] == '1') m->use_static = true;
+    const char* env = getenv("BRBD_DISABLE_COMPILED");
+    if (env && env[0] == '1') m->use_spec = false;
     env = getenv("BRBD_DISABLE_LDS");
     if (env && env[0] == '1') m->use_lds = false;
   }
@@ -316,6 +365,17 @@ int brbd_model_create(const brbd_model_desc* desc, int device, brbd_model** out)
   if (e == hipSuccess) e = upload((void**)&m->d_prog3, m->flat.prog3.data(), m->flat.prog3.size() * sizeof(Op));
   if (e == hipSuccess)
     e = upload((void**)&m->d_nvsub, m->flat.nv_subtree.data(), m->flat.nv_subtree.size() * sizeof(int));
+  if (e == hipSuccess) {
+    // model-compiled kernels: exact zero pattern first, then the dense kernels of the same tree
+    const std::string exact = model_signature(m->flat, false), dense = model_signature(m->flat, true);
+    for (int pass = 0; pass < 2 && !m->spec; ++pass)
+      for (int k = 0; k < spec_entry_count && !m->spec; ++k)
+        if ((pass == 0 ? exact : dense) == spec_entries[k]->signature) m->spec = spec_entries[k];
+    for (int a = 0; m->spec && a < 3 && e == hipSuccess; ++a) {
+      const std::vector<double> ct = pack_constants(m->flat, m->spec->algo[a]);
+      e = upload((void**)&m->d_ct[a], ct.data(), ct.size() * sizeof(double));
+    }
+  }
   if (e != hipSuccess) {
     brbd_model_destroy(m);
     return fail(BRBD_ERR_RUNTIME, std::string("uploading the model table: ") + hipGetErrorString(e));
@@ -336,6 +396,8 @@ int brbd_model_destroy(brbd_model* m) {
   if (m->d_prog) (void)hipFree(m->d_prog);
   if (m->d_prog3) (void)hipFree(m->d_prog3);
   if (m->d_nvsub) (void)hipFree(m->d_nvsub);
+  for (double* p : m->d_ct)
+    if (p) (void)hipFree(p);
   if (m->d_ws) (void)hipFree(m->d_ws);
   if (m->d_stage) (void)hipFree(m->d_stage);
   delete m;
@@ -593,13 +655,13 @@ int brbd_transpose_to_instance_major(int device, int64_t dof, int64_t B, const d
   return transpose_common(device, dof, B, src, ld_src, dst, ld_dst, stream, 0);
 }
 
-const char* brbd_model_static_topology(const brbd_model* m) {
-  return (m && m->stat) ? m->stat->name : "";
+const char* brbd_model_compiled_kernels(const brbd_model* m) {
+  return (m && m->spec) ? m->spec->name : "";
 }
 
-int brbd_model_use_static(brbd_model* m, int enabled) {
+int brbd_model_use_compiled(brbd_model* m, int enabled) {
   if (!m) return fail(BRBD_ERR_INVALID_ARGUMENT, "model handle is NULL");
-  m->use_static = enabled != 0;
+  m->use_spec = enabled != 0;
   return BRBD_OK;
 }
 

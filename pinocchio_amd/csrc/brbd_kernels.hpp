@@ -46,6 +46,7 @@ struct KArgs {
   const double* a; int64_t lda;  // RNEA: a, ABA: tau
   double* out; int64_t ldout;    // RNEA: tau, ABA: ddq, FKJ: J
   double* out2; int64_t ldout2;  // FKJ: oMi
+  const double* ctab;            // model-compiled kernels (brbd_spec.hpp): packed constant table
 };
 
 // ---- boundary matrices -------------------------------------------------------------------------
@@ -1050,7 +1051,7 @@ __global__ __launch_bounds__(WAVE) void fkjac_kernel(const KArgs A) {
 
 // =================================================================================== layout helpers
 // dof x B instance-major (x[b*ld + d]) <-> batch-major (y[d*ld + b]) through a padded LDS tile.
-__global__ __launch_bounds__(256) void transpose_kernel(const double* __restrict__ src, int64_t ld_src,
+static __global__ __launch_bounds__(256) void transpose_kernel(const double* __restrict__ src, int64_t ld_src,
                                                         double* __restrict__ dst, int64_t ld_dst,
                                                         int64_t dof, int64_t B, int to_batch_major) {
   __shared__ double tile[32][33];

@@ -13,7 +13,7 @@ from typing import Optional
 from .model import brbd_model_desc
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbrbd_hip.so")
+LIB_PATH = os.environ.get("BRBD_LIB") or os.path.join(_HERE, "libbrbd_hip.so")  # BRBD_LIB: A/B builds
 
 BRBD_OK = 0
 BRBD_ERR_INVALID_ARGUMENT = -1

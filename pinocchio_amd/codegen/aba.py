@@ -22,12 +22,19 @@ Per tree hanging off the universe: passes 1 + 2 fused in one depth-first walk, t
 """
 from __future__ import annotations
 
+import os
 from typing import List
 
 from .. import model as M
 from . import algebra as A
 from . import joints as J
 from .emit import ZERO, Emitter, V
+
+
+# Pass 3 needs sin / cos of every joint again.  Evaluating them a second time (~40 instructions)
+# is cheaper than carrying 2 more doubles per joint from pass 1 to pass 3 once the on-chip park
+# storage is full and they would travel through HBM.
+RECOMPUTE_SINCOS = os.environ.get("BRBD_CG_RESINCOS", "1") == "1"
 
 
 def chol_factor(e: Emitter, D: List[List[V]]):
@@ -95,7 +102,7 @@ def generate(mv: J.ModelView, e: Emitter) -> Emitter:
     g = None
     scpark = {}   # joint -> Park (s, c)
     hand = {}     # joint -> Park UDinv (6 nv) + Dinv u (nv)
-    contrib = {}  # joint -> Parks of finished children's (Ia 21, of 6)
+    contrib = {}  # joint -> Park of the sum of the finished children's (Ia 21, of 6)
 
     def compose(p, Rp, tp, Rl, tl):
         if p == 0:  # aba.hxx:119-122
@@ -171,7 +178,12 @@ def generate(mv: J.ModelView, e: Emitter) -> Emitter:
         pa = A.sym6_mulvec(e, Ia2, bias, of)                          # :188
         for c in range(nv):
             pa = A.vaxpy(e, u[c], UD[c], pa)                          # :189
-        contrib.setdefault(p, []).append(e.park(Ia2 + pa, "stack"))  # :190-191
+        # :190-191  oYaba[parent] += Ia, of[parent] += of: one running accumulator per parent (the
+        # first finished child starts it, later ones add to it), consumed by the parent's backward visit
+        acc = Ia2 + pa
+        if p in contrib:
+            acc = A.vadd(e, e.unpark(contrib[p]), acc)
+        contrib[p] = e.park(acc, "stack")
         return None
 
     def step_back(R, t, ov, Rl, tl, ovJ):
@@ -197,7 +209,7 @@ def generate(mv: J.ModelView, e: Emitter) -> Emitter:
             e.begin_visit("PASS3 %d" % i)
             vals = e.unpark(kin[p])
             Rp, tp, ovp, ap = [vals[0:3], vals[3:6], vals[6:9]], vals[9:12], vals[12:18], vals[18:24]
-            if i in scpark:
+            if i in scpark and not RECOMPUTE_SINCOS:
                 Rl, tl, _ = J.joint_transform(e, mv, i, sc=tuple(e.unpark(scpark[i])))
             else:
                 Rl, tl, _ = J.joint_transform(e, mv, i)
@@ -244,7 +256,7 @@ def generate(mv: J.ModelView, e: Emitter) -> Emitter:
             for k in range(nv):
                 ovJ = A.vaxpy(e, vq[k], Jc[k], ovJ)         # :126
             ov = ovJ if p == 0 else A.vadd(e, cur[2], ovJ)  # :127-128
-            if sc is not None and p != 0:
+            if sc is not None and p != 0 and not RECOMPUTE_SINCOS:
                 scpark[i] = e.park(list(sc), "hand")
             elif sc is not None and not leaf:
                 scpark[i] = e.park(list(sc), "stack")
@@ -267,8 +279,8 @@ def generate(mv: J.ModelView, e: Emitter) -> Emitter:
                 for k in range(nv):
                     ovJ = A.vaxpy(e, vq[k], Jc[k], ovJ)
             Ia, of = own_inertia(i, R, t, ov)
-            for cb in contrib.pop(i, []):
-                vals = e.unpark(cb)
+            if i in contrib:
+                vals = e.unpark(contrib.pop(i))
                 Ia = A.vadd(e, Ia, vals[:21])
                 of = A.vadd(e, of, vals[21:])
             a_root = backward(i, R, t, ov, Jc, ovJ, Ia, of)

@@ -24,9 +24,14 @@ from .emit import Emitter, plan_storage
 
 ALGOS = {"rnea": rnea.generate, "aba": aba.generate, "fkjac": fkjac.generate}
 
-# storage budgets (doubles per lane) of the park planner, per algorithm: (registers, LDS)
+# storage budgets (doubles per lane) of the park planner, per algorithm:
+# (registers for short-lived parks, LDS, registers for long-lived parks)
 # LDS: 160 KiB per CU, 4 resident waves of 64 lanes at one wave per SIMD -> 80 doubles per lane
-BUDGETS = {"rnea": (72, 80), "aba": (96, 80), "fkjac": (48, 80)}
+BUDGETS = {"rnea": (40, 80, 0), "aba": (16, 80, 0), "fkjac": (36, 80, 0)}
+for _a in list(BUDGETS):  # experiment hook: BRBD_CG_ABA="64,80"
+    _v = os.environ.get("BRBD_CG_" + _a.upper())
+    if _v:
+        BUDGETS[_a] = tuple(int(x) for x in _v.split(","))
 
 
 class Kernel:
@@ -38,11 +43,11 @@ class Kernel:
 def build_kernel(mv: joints.ModelView, algo: str, reg_budget: Optional[int] = None,
                  lds_budget: Optional[int] = None) -> Kernel:
     gen = ALGOS[algo]
-    rb, lb = BUDGETS[algo]
+    rb, lb, rl = BUDGETS[algo]
     rb = rb if reg_budget is None else reg_budget
     lb = lb if lds_budget is None else lds_budget
     dry = gen(mv, Emitter())
-    plan, lds, glb = plan_storage(dry.parks, rb, lb)
+    plan, lds, glb = plan_storage(dry.parks, rb, lb, rl)
     e = gen(mv, Emitter(plan))
     return Kernel(algo, e.text(), list(e.const_list), lds, glb, dict(e.stats), len(e.visits))
 
@@ -70,6 +75,7 @@ _CPU_SHELL = r"""
 #define PK_GLB_ST2(p, a, b) do { glb[2 * (p)] = (a); glb[2 * (p) + 1] = (b); } while (0)
 #define PK_GLB_LD2(p, a, b) do { a = glb[2 * (p)]; b = glb[2 * (p) + 1]; } while (0)
 #define VISIT_END() do { } while (0)
+#define OPAQUE(x) do { } while (0)
 static void one(const double* ct, const double* q, const double* v, const double* x, double* out,
                 double* out2, double* out3, double* lds, double* glb) {
   (void)ct; (void)q; (void)v; (void)x; (void)out; (void)out2; (void)out3; (void)lds; (void)glb;

@@ -22,6 +22,7 @@ second pass emits the loads of a parked value one visit ahead of its use.
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 MACROS = """
@@ -34,6 +35,7 @@ MACROS = """
   PK_LDS_ST2(p, a, b) / PK_LDS_LD2(p, a, b)   pair slot p of the LDS park area
   PK_GLB_ST2(p, a, b) / PK_GLB_LD2(p, a, b)   pair slot p of the global park area
   VISIT_END()           boundary between two visits (scheduling barrier on the GPU)
+  OPAQUE(x)             make the compiler forget how x was computed (no instruction)
 """
 
 
@@ -77,6 +79,12 @@ def _lit(x: float) -> str:
     return "(" + s + ")" if x < 0 else s
 
 
+# prefetch distance in visits per kind of early load (experiment hook: BRBD_CG_AHEAD="in=6,glb=6")
+AHEAD = {"ct": 0, "in": 2, "lds": 0, "glb": 2}
+for _kv in os.environ.get("BRBD_CG_AHEAD", "").split(","):
+    if "=" in _kv:
+        AHEAD[_kv.split("=")[0]] = int(_kv.split("=")[1])
+
 ZERO = V(num=0.0)
 ONE = V(num=1.0)
 
@@ -115,7 +123,7 @@ class Emitter:
         self.const_cache: Dict[tuple, V] = {}
         self.in_cache: Dict[tuple, V] = {}
         self.stats = {"fp": 0, "ld": 0, "st": 0, "ct": 0, "trans": 0}
-        self._pending_pre: List[str] = []  # early loads requested before their visit exists
+        self.opaque_regs = False  # experiment: made register pressure worse with hipcc 7.2
 
     # ---- visits --------------------------------------------------------------------------
     def begin_visit(self, label: str):
@@ -135,9 +143,11 @@ class Emitter:
     def stmt(self, line: str):
         self.visits[-1].body.append(line)
 
-    def pre(self, line: str):
-        """A load that may be issued one visit ahead of the current one."""
-        self.visits[-1].pre.append(line)
+    def pre(self, line: str, kind: str = "ct", earliest: int = 0):
+        """A load that may be issued ahead of the current visit: ``kind`` selects the prefetch
+        distance ("ct" scalar table, "in" boundary matrices, "lds" / "glb" park areas), ``earliest``
+        is the first visit it may be issued in (a park's loads come after its stores)."""
+        self.visits[-1].pre.append((line, kind, earliest))
 
     def comment(self, text: str):
         self.stmt("/* " + text + " */")
@@ -169,7 +179,7 @@ class Emitter:
         if key in self.in_cache:
             return self.in_cache[key]
         name = "%s%d_%d" % (which.lower(), k, self.vi)
-        self.pre("const double %s = IN_%s(%d);" % (name, which, k))
+        self.pre("const double %s = IN_%s(%d);" % (name, which, k), "in")
         self.stats["ld"] += 1
         v = V(name)
         self.in_cache[key] = v
@@ -314,14 +324,28 @@ class Emitter:
         if self.plan is None or pk.cls == "reg" or self.vi <= pk.start + 1:
             # (a value consumed by the very next visit is still in registers: its early load would
             # be issued before the store)
-            return list(pk.vals)
+            if self.plan is None or self.vi <= pk.start + 1 or not self.opaque_regs:
+                return list(pk.vals)
+            # A register-parked value comes back OPAQUE: otherwise the compiler proves that what is
+            # recomputed from it (a joint rotation from its sin / cos ...) equals what the forward
+            # visit computed and keeps all of that alive instead.
+            out = []
+            for v in pk.vals:
+                if v.is_num:
+                    out.append(v)
+                    continue
+                n = self._tmp()
+                self.stmt("double %s = %s; OPAQUE(%s);" % (n, v.name, n))
+                out.append(V(n, v.neg))
+            return out
         live = [v for v in pk.vals if not v.is_num]
         mac = "PK_LDS_LD2" if pk.cls == "lds" else "PK_GLB_LD2"
         names = []
         for j in range(0, len(live), 2):
             a = self._tmp()
             b = self._tmp()
-            self.pre("double %s, %s; %s(%d, %s, %s);" % (a, b, mac, pk.slot // 2 + j // 2, a, b))
+            self.pre("double %s, %s; %s(%d, %s, %s);" % (a, b, mac, pk.slot // 2 + j // 2, a, b), pk.cls,
+                     pk.start + 1)
             self.stats["ld"] += 1
             names += [a, b]
         out, j = [], 0
@@ -334,68 +358,78 @@ class Emitter:
         return out
 
     # ---- output ----------------------------------------------------------------------------------
-    def text(self, ahead: int = 1) -> str:
-        """Concatenate the visits; the early loads of visit k are issued at the start of visit
-        k - ahead."""
+    def text(self, ahead: Optional[Dict[str, int]] = None) -> str:
+        """Concatenate the visits.  The early loads of visit k are issued at the start of visit
+        k - ahead[kind] (not before their ``earliest`` visit).  With a single wave per SIMD nothing
+        else hides memory latency: HBM loads want several visits (microseconds) of distance, LDS
+        and the scalar cache one."""
+        ahead = ahead or AHEAD
         n = len(self.visits)
+        early: List[List[str]] = [[] for _ in range(n)]
+        for k in range(n):
+            for line, kind, earliest in self.visits[k].pre:
+                early[max(0, earliest, k - ahead.get(kind, 1))].append(line)
         lines: List[str] = []
         for k in range(n):
-            if k == 0:
-                for j in range(0, min(ahead, n)):
-                    lines += self.visits[j].pre
-            if k + ahead < n:
-                lines += self.visits[k + ahead].pre
+            lines += early[k]
             lines.append("/* ---- visit %d: %s ---- */" % (k, self.visits[k].label))
             lines += self.visits[k].body
             lines.append("VISIT_END();")
         return "\n".join(lines) + "\n"
 
 
-def plan_storage(parks: Sequence[Park], reg_budget: int, lds_budget: int,
-                 reg_hints: Sequence[str] = ("stack", "hand"), order: Sequence[str] = ()):
-    """Assign every park a storage class.  Greedy over start visits: registers while the live
-    register-parked doubles stay under ``reg_budget``, then LDS (first-fit interval allocation,
-    pair granularity), then the wave-private global workspace.  A slot may be reused by a park that
-    starts in the visit its previous owner was last read in (those loads are issued earlier).
-    Returns (plan, lds_doubles, glb_doubles)."""
-    plan: Dict[int, Tuple[str, int]] = {}
-    live_reg: List[Park] = []
-    lds_used: List[Tuple[int, int, int]] = []  # (slot, size, end)
-    glb_used: List[Tuple[int, int, int]] = []
-    lds_max = glb_max = 0
+def plan_storage(parks: Sequence[Park], reg_short: int, lds_budget: int, reg_long: int = 0):
+    """Assign every park a storage class: ("reg" | "lds" | "glb", first slot).
 
-    def first_fit(used, size, start, limit):
-        used[:] = [u for u in used if u[2] > start]
+    * A park consumed by the very next visit stays in registers (chains hand state over for free).
+    * Short-lived parks (hint "stack": path state, contributions of finished subtrees) are placed
+      first: registers while fewer than ``reg_short`` such doubles are live, then LDS, then the
+      wave-private global workspace.
+    * Long-lived parks (hint "hand": what ABA's pass 3 needs from pass 2) then fill what is left:
+      up to ``reg_long`` live doubles in registers (the allocator keeps values with distant uses in
+      AGPRs), then the LDS slots the stack leaves free during their lifetime, then global.
+    LDS / global slots are allocated with interval first-fit at pair granularity; a slot may be
+    reused by a park that starts in the visit its previous owner was last read in (those loads are
+    issued one visit earlier).  Returns (plan, lds_doubles, glb_doubles)."""
+    plan: Dict[int, Tuple[str, int]] = {}
+    used = {"lds": [], "glb": []}  # (slot, size, start, end)
+    top = {"lds": 0, "glb": 0}
+
+    def size_of(pk):
+        n = sum(1 for v in pk.vals if not v.is_num)
+        return n + (n & 1)
+
+    def first_fit(cls, size, start, end, limit):
+        busy = sorted((s, sz) for s, sz, a, b in used[cls] if a < end and start < b)
         pos = 0
-        for s, sz, _ in sorted(used):
+        for s, sz in busy:
             if pos + size <= s:
                 break
             pos = max(pos, s + sz)
         if limit is not None and pos + size > limit:
             return -1
+        used[cls].append((pos, size, start, end))
+        top[cls] = max(top[cls], pos + size)
         return pos
 
-    for pk in sorted(parks, key=lambda p: (p.start, p.pid)):
-        size = sum(1 for v in pk.vals if not v.is_num)
-        size += size & 1
-        if size == 0 or pk.end <= pk.start + 1:
-            # consumed by the very next visit (or never): a register hand-over
-            plan[pk.pid] = ("reg", 0)
-            continue
-        live_reg = [p for p in live_reg if p.end > pk.start]
-        reg_now = sum(sum(1 for v in p.vals if not v.is_num) for p in live_reg)
-        if pk.hint in reg_hints and reg_now + size <= reg_budget:
-            plan[pk.pid] = ("reg", 0)
-            live_reg.append(pk)
-            continue
-        pos = first_fit(lds_used, size, pk.start, lds_budget)
-        if pos >= 0:
-            plan[pk.pid] = ("lds", pos)
-            lds_used.append((pos, size, pk.end))
-            lds_max = max(lds_max, pos + size)
-            continue
-        pos = first_fit(glb_used, size, pk.start, None)
-        plan[pk.pid] = ("glb", pos)
-        glb_used.append((pos, size, pk.end))
-        glb_max = max(glb_max, pos + size)
-    return plan, lds_max, glb_max
+    def reg_live(pk, placed):
+        # register-parked doubles live at any time during pk's lifetime (upper bound: all overlapping)
+        return sum(size_of(p) for p in placed if p.start < pk.end and pk.start < p.end)
+
+    for hint, budget in (("stack", reg_short), ("hand", reg_long)):
+        placed = []
+        for pk in sorted((p for p in parks if p.hint == hint), key=lambda p: (p.start, p.pid)):
+            size = size_of(pk)
+            if size == 0 or pk.end <= pk.start + 1:
+                plan[pk.pid] = ("reg", 0)
+                continue
+            if reg_live(pk, placed) + size <= budget:
+                plan[pk.pid] = ("reg", 0)
+                placed.append(pk)
+                continue
+            pos = first_fit("lds", size, pk.start, pk.end, lds_budget)
+            if pos >= 0:
+                plan[pk.pid] = ("lds", pos)
+                continue
+            plan[pk.pid] = ("glb", first_fit("glb", size, pk.start, pk.end, None))
+    return plan, top["lds"], top["glb"]

@@ -18,7 +18,7 @@ from .emit import ZERO, Emitter
 def generate(mv: J.ModelView, e: Emitter) -> Emitter:
     va = {}       # joint -> Park of v(6) + a_gf(6)
     fpark = {}    # joint -> Park of f(6) + (s, c) | f(6) + R(9) + t(3)
-    contrib = {}  # joint -> Parks of finished children's liMi.act(f)
+    contrib = {}  # joint -> Park of the sum of the finished children's liMi.act(f)
 
     def backward(i, f, R, t):
         S = J.subspace(e, mv, i)
@@ -29,7 +29,10 @@ def generate(mv: J.ModelView, e: Emitter) -> Emitter:
             e.out(iv + k, e.fma(arm, e.inp("X", iv + k), tau[k]) if not arm.is_zero() else tau[k])  # :158
         p = mv.parents[i]
         if p != 0:  # :105-106
-            contrib.setdefault(p, []).append(e.park(A.act_force(e, R, t, f), "stack"))
+            up = A.act_force(e, R, t, f)
+            if p in contrib:  # running sum of the finished children
+                up = A.vadd(e, e.unpark(contrib[p]), up)
+            contrib[p] = e.park(up, "stack")
 
     for kind, i in J.visit_program(mv):
         p = mv.parents[i]
@@ -68,7 +71,7 @@ def generate(mv: J.ModelView, e: Emitter) -> Emitter:
                 R, t, _ = J.joint_transform(e, mv, i, sc=(keep[6], keep[7]))
             else:
                 R, t = [keep[6:9], keep[9:12], keep[12:15]], keep[15:18]
-            for cb in contrib.pop(i, []):
-                f = A.vadd(e, f, e.unpark(cb))
+            if i in contrib:
+                f = A.vadd(e, f, e.unpark(contrib.pop(i)))
             backward(i, f, R, t)
     return e

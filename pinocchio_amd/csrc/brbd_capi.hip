@@ -232,12 +232,18 @@ int launch_algo(brbd_model* m, int algo, KArgs& A, int layout, hipStream_t strea
   if (sk) {
     if (algo == BRBD_ALGO_FK_JAC) variant = (A.out ? 1 : 0) | (A.out2 ? 2 : 0);
     else variant = 0;
-    auto fits = [&](int64_t ld, int64_t dof) { return (double)ld * (double)dof * 8.0 < 4294967296.0; };
-    if (layout == BRBD_BATCH_MAJOR) {
-      bool ok = fits(A.ldq, F.nq);
-      if (algo != BRBD_ALGO_FK_JAC) ok = ok && fits(A.ldv, F.nv) && fits(A.lda, F.nv) && fits(A.ldout, F.nv);
-      else ok = ok && (!A.out || fits(A.ldout, 6 * (int64_t)F.nv)) && (!A.out2 || fits(A.ldout2, 12 * (int64_t)F.njoints));
-      if (!ok) sk = nullptr;
+    // buffer ranges: every matrix must span less than 4 GiB (32-bit byte offsets)
+    const int64_t dofs[5] = {F.nq, F.nv, F.nv, algo == BRBD_ALGO_FK_JAC ? 6 * (int64_t)F.nv : F.nv,
+                             12 * (int64_t)F.njoints};
+    const void* ptrs[5] = {A.q, A.v, A.a, A.out, A.out2};
+    const int64_t lds_[5] = {A.ldq, A.ldv, A.lda, A.ldout, A.ldout2};
+    for (int k = 0; k < 5 && sk; ++k) {
+      A.nb[k] = 0;
+      if (!ptrs[k]) continue;
+      const double span = 8.0 * (layout == BRBD_BATCH_MAJOR ? (double)lds_[k] * (double)dofs[k]
+                                                             : (double)lds_[k] * (double)A.B);
+      if (span >= 4294967295.0) sk = nullptr;
+      else A.nb[k] = (uint32_t)span;
     }
     if (sk && !sk->fn[layout][variant]) sk = nullptr;
   }
@@ -277,16 +283,30 @@ int launch_algo(brbd_model* m, int algo, KArgs& A, int layout, hipStream_t strea
     A.ctab = m->d_ct[algo];
   }
   A.lds_cap = lds_cap;
+  // table-driven kernels: grid-stride over the tiles with as many waves as are resident.
+  // model-compiled kernels: one tile per workgroup; launched in chunks when they park state in
+  // the wave-private global area, so that the area stays bounded (8 rounds of resident waves).
   int64_t grid = A.ntiles < resident ? A.ntiles : resident;
+  if (stat) {
+    int64_t chunk = sk->glb_doubles > 0 ? resident * 8 : A.ntiles;
+    const int64_t cap = (int64_t)(4000000000.0 / ((double)per_lane * WAVE * 8));  // 32-bit park offsets
+    if (chunk > cap) chunk = cap;
+    grid = A.ntiles < chunk ? A.ntiles : chunk;
+  }
   A.ws_stride = (int64_t)per_lane * WAVE;
   int rc = ensure_ws(m, (size_t)grid * A.ws_stride);
   if (rc) return rc;
   A.ws = m->d_ws;
+  A.ws_bytes = (uint32_t)((size_t)grid * A.ws_stride * 8);
   Timer tm{m, algo, stream};
   if ((rc = tm.begin())) return rc;
   const dim3 g((unsigned)grid), b(WAVE);
   if (stat) {
-    hipLaunchKernelGGL(sfn, g, b, 0, stream, A);
+    for (int64_t t0 = 0; t0 < A.ntiles; t0 += grid) {
+      A.tile0 = t0;
+      const int64_t n = A.ntiles - t0 < grid ? A.ntiles - t0 : grid;
+      hipLaunchKernelGGL(sfn, dim3((unsigned)n), b, 0, stream, A);
+    }
   } else if (algo == BRBD_ALGO_RNEA) {
     if (layout == BRBD_BATCH_MAJOR) hipLaunchKernelGGL(rnea_kernel<1>, g, b, lds_bytes, stream, A);
     else hipLaunchKernelGGL(rnea_kernel<0>, g, b, lds_bytes, stream, A);

@@ -47,6 +47,9 @@ struct KArgs {
   double* out; int64_t ldout;    // RNEA: tau, ABA: ddq, FKJ: J
   double* out2; int64_t ldout2;  // FKJ: oMi
   const double* ctab;            // model-compiled kernels (brbd_spec.hpp): packed constant table
+  int64_t tile0;                 //   first tile of this launch (the host launches in chunks)
+  uint32_t nb[5];                //   bytes spanned by q, v, a/tau, out, out2 (buffer ranges; 0 = absent)
+  uint32_t ws_bytes;             //   bytes of the global park area of this launch
 };
 
 // ---- boundary matrices -------------------------------------------------------------------------

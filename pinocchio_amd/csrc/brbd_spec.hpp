@@ -9,10 +9,11 @@
 //   * IN_* / OUT*: the boundary matrices in either layout of include/brbd.h (Mat<LAYOUT>);
 //   * PK_LDS_* / PK_GLB_*: the park areas the generator's storage plan assigned: LDS
 //     ([pair][lane] double2 -> ds_read/write_b128) and a wave-private global workspace
-//     ([pair][lane] double2 -> global_load/store_dwordx4, coalesced 1 KiB rows);
+//     ([pair][lane] double2 -> buffer_load/store_dwordx4, coalesced 1 KiB rows);
 //   * VISIT_END(): scheduling barrier between visits, so that the early loads the generator
 //     placed one visit ahead stay there and register pressure stays per-visit.
-// One lane = one instance, one wave = one workgroup, grid-stride over tiles of 64 instances.
+// One lane = one instance, one wave = one workgroup = one tile of 64 instances; the host launches
+// at most `chunk` tiles at a time so that the wave-private global park area stays bounded.
 #pragma once
 #include "brbd_kernels.hpp"
 
@@ -35,43 +36,60 @@ struct SpecEntry {
   SpecKernel algo[3];     // BRBD_ALGO_RNEA, BRBD_ALGO_ABA, BRBD_ALGO_FK_JAC
 };
 
-// ---- boundary matrices of the model-compiled kernels ------------------------------------------
-// BATCH_MAJOR: one buffer resource per matrix and tile (base = first instance of the tile), element
-// (d, lane) at byte d*ld8 + lane8: `buffer_load_dwordx2 v, v_lane8, s[rsrc], s_off offen` with
-// s_off = d * ld8 one s_mul_i32 away -- two issue slots per element and no 64-bit address math.
-// The host only selects these kernels when dof * ld * 8 < 2^32 for every matrix.
+// ---- memory access of the model-compiled kernels ------------------------------------------------
+// Every vector memory access goes through a buffer resource with an exact byte range
+// (num_records): `buffer_load/store v, v_off, s[rsrc], s_off offen offset:imm`.  Two issue slots
+// per element at most (an s_mul_i32 for s_off), no 64-bit address arithmetic, and an offset that
+// is out of range is dropped by the hardware instead of faulting.  The host only selects these
+// kernels when every matrix spans less than 4 GiB (32-bit byte offsets).
 // Lanes past the end of the batch are clamped onto the last instance (same values re-stored).
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+DI __amdgpu_buffer_rsrc_t spec_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
 template <int LAYOUT>
 struct SpecMat;
 template <>
-struct SpecMat<1> {
+struct SpecMat<1> {  // BATCH_MAJOR: element (d, b) at byte d * ld8 + b * 8
   __amdgpu_buffer_rsrc_t r;
-  unsigned lane8;
-  DI SpecMat(const double* base, int64_t ld, int64_t tile, int64_t B, int lane) {
-    (void)ld;
-    r = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(base + tile * WAVE), 0, 0xFFFFFFFFu, 0x00020000);
-    const int64_t left = B - tile * WAVE;  // >= 1
-    lane8 = ((int64_t)lane < left ? (unsigned)lane : (unsigned)(left - 1)) * 8u;
+  unsigned voff;
+  DI SpecMat(const double* base, unsigned bytes, unsigned ld8, int64_t b) : r(spec_rsrc(base, bytes)) {
+    (void)ld8;
+    voff = (unsigned)b * 8u;
   }
   DI double get(int d, unsigned ld8) const {
-    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, lane8, (unsigned)d * ld8, 0));
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, (unsigned)d * ld8, 0));
   }
   DI void put(int d, unsigned ld8, double x) const {
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, x), r, lane8, (unsigned)d * ld8, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, x), r, voff, (unsigned)d * ld8, 0);
   }
 };
 template <>
-struct SpecMat<0> {  // INSTANCE_MAJOR: per-lane row pointer, element index is an immediate offset
-  double* row;
-  DI SpecMat(const double* base, int64_t ld, int64_t tile, int64_t B, int lane) {
-    int64_t b = tile * WAVE + lane;
-    if (b >= B) b = B - 1;
-    row = const_cast<double*>(base) + b * ld;
+struct SpecMat<0> {  // INSTANCE_MAJOR: element (d, b) at byte b * ld8 + d * 8 (immediate offset)
+  __amdgpu_buffer_rsrc_t r;
+  unsigned voff;
+  DI SpecMat(const double* base, unsigned bytes, unsigned ld8, int64_t b) : r(spec_rsrc(base, bytes)) {
+    voff = (unsigned)b * ld8;
   }
-  DI double get(int d, unsigned) const { return row[d]; }
-  DI void put(int d, unsigned, double x) const { row[d] = x; }
+  DI double get(int d, unsigned) const {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff + (unsigned)d * 8u, 0, 0));
+  }
+  DI void put(int d, unsigned, double x) const {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, x), r, voff + (unsigned)d * 8u, 0, 0);
+  }
 };
+DI void spec_park_st(__amdgpu_buffer_rsrc_t r, unsigned voff, int p, double a, double b) {
+  const v2u x = __builtin_bit_cast(v2u, a), y = __builtin_bit_cast(v2u, b);
+  const v4u w = {x.x, x.y, y.x, y.y};
+  __builtin_amdgcn_raw_buffer_store_b128(w, r, voff + (unsigned)p * (WAVE * 16u), 0, 0);
+}
+DI void spec_park_ld(__amdgpu_buffer_rsrc_t r, unsigned voff, int p, double& a, double& b) {
+  const v4u w = __builtin_amdgcn_raw_buffer_load_b128(r, voff + (unsigned)p * (WAVE * 16u), 0, 0);
+  const v2u x = {w.x, w.y}, y = {w.z, w.w};
+  a = __builtin_bit_cast(double, x);
+  b = __builtin_bit_cast(double, y);
+}
 
 // sin and cos of a joint angle in ~40 instructions: 3-term Cody-Waite reduction by pi/2 carried by
 // FMAs (exact products), fdlibm's minimax kernels on [-pi/4, pi/4] (k_sin.c / k_cos.c coefficients),
@@ -80,7 +98,10 @@ struct SpecMat<0> {  // INSTANCE_MAJOR: per-lane row pointer, element index is a
 // calls glibc sincos.)
 DI void spec_sincos(double x, double& so, double& co) {
   if (__builtin_expect(!(__builtin_fabs(x) < 1.0e9), 0)) {
-    sincos(x, &so, &co);
+    // separate calls: sincos() hands its second result back through a private pointer, which
+    // sometimes survives as a stack object (scratch); out of line it costs more than it saves
+    so = sin(x);
+    co = cos(x);
     return;
   }
   const double n = __builtin_rint(x * 0.63661977236758138);
@@ -119,42 +140,44 @@ DI void spec_sincos(double x, double& so, double& co) {
 #define FMA(a, b, c) __builtin_fma(a, b, c)
 #define PK_LDS_ST2(p, a, b) lds2[(p) * WAVE] = make_double2(a, b)
 #define PK_LDS_LD2(p, a, b) do { const double2 t_ = lds2[(p) * WAVE]; a = t_.x; b = t_.y; } while (0)
-#define PK_GLB_ST2(p, a, b) \
-  *reinterpret_cast<double2*>(reinterpret_cast<char*>(ws2 + (p) * WAVE) + lane16) = make_double2(a, b)
-#define PK_GLB_LD2(p, a, b)                                                                              \
-  do {                                                                                                   \
-    const double2 t_ = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(ws2 + (p) * WAVE) + lane16); \
-    a = t_.x; b = t_.y;                                                                                  \
-  } while (0)
-// Visit boundary: nothing is scheduled across it, and the uniform values every scalar load / offset
-// is derived from are made opaque again, so neither LICM (the tile loop) nor the scheduler can hoist
-// the table loads of later visits up front (that is what cost 2000 SGPR spills in the template-
-// unrolled experiment).
+#define PK_GLB_ST2(p, a, b) spec_park_st(wsr, wsoff, p, a, b)
+#define PK_GLB_LD2(p, a, b) spec_park_ld(wsr, wsoff, p, a, b)
+// Visit boundary: nothing is scheduled across it, so the table loads of later visits are not
+// hoisted up front (that is what cost 2000 SGPR spills in the template-unrolled experiment).
+#define OPAQUE(x) asm volatile("" : "+v"(x))
+// (Making the uniform bases opaque at every visit -- asm volatile("" : "+s"(ct), ...) -- kept LICM
+// from hoisting the table loads out of a tile loop, but tied up SGPRs and, with hipcc 7.2, produced
+// kernels that miscomputed under SGPR spilling.  The shells now run ONE tile per workgroup: there
+// is no loop to hoist out of, and the scheduling barrier alone keeps the loads in their visit.)
+#define BRBD_LAUNDER() do { } while (0)
+#define BRBD_CAT2(a, b) a##b
+#define BRBD_CAT(a, b) BRBD_CAT2(a, b)
 #define VISIT_END()                                                                                  \
   do {                                                                                               \
     __builtin_amdgcn_sched_barrier(0);                                                               \
-    asm volatile("" : "+s"(ct), "+s"(ldq8), "+s"(ldv8), "+s"(ldx8), "+s"(ldo8), "+s"(ldo28));        \
+    BRBD_LAUNDER();                                                                                  \
   } while (0)
 
-// everything before the tile loop
+// everything before the body: one tile of 64 instances per workgroup
 #define BRBD_SPEC_PROLOGUE(LDS_PAIRS)                                                                \
   const int lane = threadIdx.x;                                                                      \
   const double BRBD_CONSTANT* ct = as_constant(A.ctab);                                              \
   __shared__ double2 lds_area[(LDS_PAIRS) > 0 ? (LDS_PAIRS) * WAVE : 1];                             \
   double2* const lds2 = lds_area + lane;                                                             \
-  double2* const ws2 = reinterpret_cast<double2*>(A.ws + (int64_t)blockIdx.x * A.ws_stride);         \
-  const unsigned lane16 = (unsigned)lane * 16u;                                                      \
-  unsigned ldq8 = (unsigned)A.ldq * 8u, ldv8 = (unsigned)A.ldv * 8u, ldx8 = (unsigned)A.lda * 8u;    \
-  unsigned ldo8 = (unsigned)A.ldout * 8u, ldo28 = (unsigned)A.ldout2 * 8u;                           \
-  (void)lds2; (void)ws2; (void)lane16;
+  const __amdgpu_buffer_rsrc_t wsr = spec_rsrc(A.ws, A.ws_bytes);                                    \
+  const unsigned wsoff = blockIdx.x * (unsigned)(A.ws_stride * 8) + (unsigned)lane * 16u;            \
+  const unsigned ldq8 = (unsigned)A.ldq * 8u, ldv8 = (unsigned)A.ldv * 8u, ldx8 = (unsigned)A.lda * 8u; \
+  const unsigned ldo8 = (unsigned)A.ldout * 8u, ldo28 = (unsigned)A.ldout2 * 8u;                     \
+  (void)lds2; (void)wsr; (void)wsoff;
 
 #define BRBD_SPEC_TILE(LAYOUT)                                                                       \
-  const SpecMat<LAYOUT> mq(A.q, A.ldq, tile, A.B, lane);                                             \
-  const SpecMat<LAYOUT> mv(A.v ? A.v : A.q, A.ldv, tile, A.B, lane);                                 \
-  const SpecMat<LAYOUT> mx(A.a ? A.a : A.q, A.lda, tile, A.B, lane);                                 \
-  const SpecMat<LAYOUT> mo(A.out ? A.out : A.out2, A.ldout, tile, A.B, lane);                        \
-  const SpecMat<LAYOUT> mo2(A.out2 ? A.out2 : A.out, A.ldout2, tile, A.B, lane);                     \
-  asm volatile("" : "+s"(ct), "+s"(ldq8), "+s"(ldv8), "+s"(ldx8), "+s"(ldo8), "+s"(ldo28));          \
+  int64_t inst = tile * WAVE + lane;                                                                 \
+  if (inst >= A.B) inst = A.B - 1;                                                                   \
+  const SpecMat<LAYOUT> mq(A.q, A.nb[0], ldq8, inst);                                                \
+  const SpecMat<LAYOUT> mv(A.v, A.nb[1], ldv8, inst);                                                \
+  const SpecMat<LAYOUT> mx(A.a, A.nb[2], ldx8, inst);                                                \
+  const SpecMat<LAYOUT> mo(A.out, A.nb[3], ldo8, inst);                                              \
+  const SpecMat<LAYOUT> mo2(A.out2, A.nb[4], ldo28, inst);                                           \
   (void)mv; (void)mx; (void)mo; (void)mo2;
 
 }  // namespace brbd

@@ -296,3 +296,106 @@ def test_transposes_and_kernel_timing(torch_mod):
     assert n == 3 and 0 < ms < 1000
     assert dm.kernel_time(capi.ALGO_RNEA) == (0, 0.0)
     pool.release()
+
+
+# ---- model-compiled kernels (pinocchio_amd/codegen, csrc/brbd_spec.hpp) --------------------------
+BUILTIN_NAMES = ["simple_humanoid", "manipulator", "arm7", "quadruped", "talos_like", "baxter_simple"]
+
+
+def _perturbed(model):
+    """Same tree and joint kinds, every placement / inertia generic: must select the dense kernels."""
+    rng = np.random.default_rng(5)
+    m = model.copy()
+    for i in range(1, m.njoints):
+        a = rng.uniform(-0.3, 0.3, 3)
+        ca, sa = np.cos(a), np.sin(a)
+        Rx = np.array([[1, 0, 0], [0, ca[0], -sa[0]], [0, sa[0], ca[0]]])
+        Ry = np.array([[ca[1], 0, sa[1]], [0, 1, 0], [-sa[1], 0, ca[1]]])
+        Rz = np.array([[ca[2], -sa[2], 0], [sa[2], ca[2], 0], [0, 0, 1]])
+        P = m.jointPlacements[i].copy()
+        P[:3, :3] = P[:3, :3] @ Rx @ Ry @ Rz
+        P[:3, 3] += rng.uniform(0.01, 0.05, 3)
+        m.jointPlacements[i] = P
+        Y = m.inertias[i]
+        A_ = rng.uniform(-1, 1, (3, 3))
+        m.inertias[i] = M.Inertia(Y.mass * 1.1 + 0.1, Y.lever + rng.uniform(0.01, 0.02, 3),
+                                  Y.inertia + A_ @ A_.T * 0.01)
+    return m
+
+
+def _check_all(pool, model, O, B=130, seed=17):
+    """Every algorithm in both boundary layouts (each is a kernel of its own) against the oracle."""
+    q, v, a = inputs(model, B, seed)
+    tau_ref = O.rnea(q, v, a)
+    ddq_ref = O.aba(q, v, tau_ref)
+    Jr, Mr = O.fk_jacobians(q)
+    for order in "FC":
+        qq, vv, aa, tt = (np.asarray(x, order=order) for x in (q, v, a, tau_ref))
+        assert rel_err_cols(parallel.rneaInParallel(1, pool, qq, vv, aa), tau_ref).max() < TOL_RNEA
+        assert rel_err_cols(parallel.abaInParallel(1, pool, qq, vv, tt), ddq_ref).max() < TOL_ABA
+        J, oMi = parallel.computeJointJacobians(pool, qq, want_oMi=True)
+        assert np.abs(J - Jr).max() < TOL_KIN and np.abs(oMi - Mr).max() < TOL_KIN
+        assert np.abs(parallel.computeJointJacobians(pool, qq) - Jr).max() < TOL_KIN  # J only
+        assert np.abs(parallel.forwardKinematics(pool, qq) - Mr).max() < TOL_KIN      # oMi only
+
+
+@pytest.mark.parametrize("name", BUILTIN_NAMES)
+def test_kernel_selection_pattern_dense_table(name):
+    """Registered models run on the kernels compiled for them ("_p": zero pattern folded); a model
+    with the same tree but generic constants selects the dense kernels ("_d"); forcing the
+    table-driven kernels gives the same results.  All three against the oracle."""
+    model = S.build(name)
+    pool = parallel.ModelPool(model, 1)
+    dm = pool.device_model(0)
+    # baxter_simple is not registered by default (codegen/build.py: REGISTERED)
+    assert dm.compiled_kernels() == (name + "_p" if name != "baxter_simple" else "")
+    O = oracle.Oracle(model)
+    _check_all(pool, model, O)
+    dm.use_compiled(False)
+    _check_all(pool, model, O)
+    dm.use_compiled(True)
+    pool.release()
+    pm = _perturbed(model)
+    pool = parallel.ModelPool(pm, 1)
+    # dense kernels are only built on request (BRBD_SPEC_VARIANTS=p,d); otherwise table-driven
+    assert pool.device_model(0).compiled_kernels() in (name + "_d", "")
+    _check_all(pool, pm, oracle.Oracle(pm))
+    pool.release()
+
+
+def test_unregistered_model_uses_table_driven_kernels():
+    pool = parallel.ModelPool(S.random_tree(100, 8), 1)
+    assert pool.device_model(0).compiled_kernels() == ""
+    pool.release()
+
+
+def test_compiled_kernels_armature_and_gravity_change_selection():
+    """Armature and gravity patterns are part of the signature: a registered tree with armature
+    falls back to the table-driven kernels and still matches the oracle."""
+    model = S.quadruped()
+    model.armature = np.linspace(0.05, 0.2, model.nv)
+    pool = parallel.ModelPool(model, 1)
+    assert pool.device_model(0).compiled_kernels() == ""
+    _check_all(pool, model, oracle.Oracle(model))
+    pool.release()
+    model = S.quadruped()
+    model.gravity = np.array([0.3, -0.2, -9.0])
+    pool = parallel.ModelPool(model, 1)
+    assert pool.device_model(0).compiled_kernels() == ""
+    _check_all(pool, model, oracle.Oracle(model))
+    pool.release()
+
+
+def test_compiled_kernels_huge_angles():
+    """|q| >= 1e9 takes the library path of spec_sincos; moderate angles the Cody-Waite path."""
+    model = S.arm7()
+    pool = parallel.ModelPool(model, 1)
+    O = oracle.Oracle(model)
+    q, v, a = inputs(model, 64, 23)
+    q[0, :16] *= 1.0e4
+    q[1, 16:32] *= 3.0e9
+    q[2, 32:48] = -7.0e12
+    assert rel_err_cols(parallel.rneaInParallel(1, pool, q, v, a), O.rnea(q, v, a)).max() < 1e-9
+    J, _ = parallel.computeJointJacobians(pool, q), None
+    assert np.abs(J - O.fk_jacobians(q)[0]).max() < 1e-9
+    pool.release()

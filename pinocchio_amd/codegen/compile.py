@@ -27,7 +27,7 @@ ALGOS = {"rnea": rnea.generate, "aba": aba.generate, "fkjac": fkjac.generate}
 # storage budgets (doubles per lane) of the park planner, per algorithm:
 # (registers for short-lived parks, LDS, registers for long-lived parks)
 # LDS: 160 KiB per CU, 4 resident waves of 64 lanes at one wave per SIMD -> 80 doubles per lane
-BUDGETS = {"rnea": (40, 80, 0), "aba": (16, 80, 0), "fkjac": (36, 80, 0)}
+BUDGETS = {"rnea": (40, 80, 0), "aba": (16, 80, 100), "fkjac": (36, 80, 0)}
 for _a in list(BUDGETS):  # experiment hook: BRBD_CG_ABA="64,80"
     _v = os.environ.get("BRBD_CG_" + _a.upper())
     if _v:

@@ -79,8 +79,8 @@ def _lit(x: float) -> str:
     return "(" + s + ")" if x < 0 else s
 
 
-# prefetch distance in visits per kind of early load (experiment hook: BRBD_CG_AHEAD="in=6,glb=6")
-AHEAD = {"ct": 0, "in": 2, "lds": 0, "glb": 2}
+# prefetch distance in statements per kind of early load (experiment hook: BRBD_CG_AHEAD="in=800")
+AHEAD = {"ct": 60, "in": 400, "lds": 0, "glb": 400}
 for _kv in os.environ.get("BRBD_CG_AHEAD", "").split(","):
     if "=" in _kv:
         AHEAD[_kv.split("=")[0]] = int(_kv.split("=")[1])
@@ -359,16 +359,24 @@ class Emitter:
 
     # ---- output ----------------------------------------------------------------------------------
     def text(self, ahead: Optional[Dict[str, int]] = None) -> str:
-        """Concatenate the visits.  The early loads of visit k are issued at the start of visit
-        k - ahead[kind] (not before their ``earliest`` visit).  With a single wave per SIMD nothing
-        else hides memory latency: HBM loads want several visits (microseconds) of distance, LDS
-        and the scalar cache one."""
+        """Concatenate the visits.  An early load of visit k is issued at the start of the latest
+        visit that lies at least ahead[kind] STATEMENTS (~ instructions, 4 cycles each with one
+        wave per SIMD) before visit k, but not before its ``earliest`` visit.  With a single wave per
+        SIMD nothing else hides memory latency: HBM wants thousands of cycles of distance, LDS and
+        the scalar cache a few hundred.  (Visits differ in length by 20x, so a distance counted in
+        visits either starves the long ones or floods the registers in the short ones.)"""
         ahead = ahead or AHEAD
         n = len(self.visits)
+        size = [len(v.body) for v in self.visits]
         early: List[List[str]] = [[] for _ in range(n)]
         for k in range(n):
             for line, kind, earliest in self.visits[k].pre:
-                early[max(0, earliest, k - ahead.get(kind, 1))].append(line)
+                want = ahead.get(kind, 0)
+                j, dist = k, 0
+                while j > 0 and j > earliest and dist < want:
+                    j -= 1
+                    dist += size[j]
+                early[max(j, 0)].append(line)
         lines: List[str] = []
         for k in range(n):
             lines += early[k]

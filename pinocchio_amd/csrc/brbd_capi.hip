@@ -302,10 +302,27 @@ int launch_algo(brbd_model* m, int algo, KArgs& A, int layout, hipStream_t strea
   if ((rc = tm.begin())) return rc;
   const dim3 g((unsigned)grid), b(WAVE);
   if (stat) {
+    // profiling builds only (-DBRBD_SPEC_TRACE): per-visit cycle stamps of wave 0, dumped to stderr
+    static const bool trace = getenv("BRBD_TRACE") && getenv("BRBD_TRACE")[0] == '1';
+    long long* d_trace = nullptr;
+    A.prog3 = nullptr;
+    if (trace && hipMalloc(&d_trace, 4096 * sizeof(long long)) == hipSuccess) {
+      (void)hipMemset(d_trace, 0, 4096 * sizeof(long long));
+      A.prog3 = reinterpret_cast<const Op*>(d_trace);
+    }
     for (int64_t t0 = 0; t0 < A.ntiles; t0 += grid) {
       A.tile0 = t0;
       const int64_t n = A.ntiles - t0 < grid ? A.ntiles - t0 : grid;
       hipLaunchKernelGGL(sfn, dim3((unsigned)n), b, 0, stream, A);
+    }
+    if (d_trace) {
+      std::vector<long long> h(4096);
+      (void)hipStreamSynchronize(stream);
+      (void)hipMemcpy(h.data(), d_trace, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
+      (void)hipFree(d_trace);
+      fprintf(stderr, "BRBD_TRACE algo %d layout %d:", algo, layout);
+      for (size_t k = 0; k < h.size() && h[k]; ++k) fprintf(stderr, " %lld", k ? h[k] - h[k - 1] : 0LL);
+      fprintf(stderr, "\n");
     }
   } else if (algo == BRBD_ALGO_RNEA) {
     if (layout == BRBD_BATCH_MAJOR) hipLaunchKernelGGL(rnea_kernel<1>, g, b, lds_bytes, stream, A);

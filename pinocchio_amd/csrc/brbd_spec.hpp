@@ -91,23 +91,21 @@ DI void spec_park_ld(__amdgpu_buffer_rsrc_t r, unsigned voff, int p, double& a, 
   b = __builtin_bit_cast(double, y);
 }
 
-// sin and cos of a joint angle in ~40 instructions: 3-term Cody-Waite reduction by pi/2 carried by
-// FMAs (exact products), fdlibm's minimax kernels on [-pi/4, pi/4] (k_sin.c / k_cos.c coefficients),
-// quadrant fix-up.  Max abs error 2.3e-16 against glibc for |x| < 1e9 (tools/ubench/sincos_check.c);
-// larger arguments, inf and nan take the device library's path.  (reference: math/sincos.hpp:47-61
-// calls glibc sincos.)
+// sin and cos of a joint angle in ~45 straight-line instructions: 3-term Cody-Waite reduction by
+// pi/2 carried by FMAs (exact products), fdlibm's minimax kernels on [-pi/4, pi/4] (k_sin.c /
+// k_cos.c coefficients), quadrant fix-up.  Max abs error 2.3e-16 against glibc
+// (tools/ubench/sincos_check.c).  Deliberately BRANCH-FREE: the compiled kernels stream through
+// their code once, so every taken branch (e.g. around an inlined large-argument path) lands on an
+// instruction-cache miss -- measured at ~1000 cycles per joint, more than the joint's arithmetic.
+// Valid for |x| < 2^50 rad; beyond that (and for inf / nan) the result is NaN, where the reference
+// (math/sincos.hpp:47-61 -> glibc) returns the sine of the rounded double.  Models whose inputs can
+// be that large run on the table-driven kernels (brbd_model_use_compiled(m, 0)).
 DI void spec_sincos(double x, double& so, double& co) {
-  if (__builtin_expect(!(__builtin_fabs(x) < 1.0e9), 0)) {
-    // separate calls: sincos() hands its second result back through a private pointer, which
-    // sometimes survives as a stack object (scratch); out of line it costs more than it saves
-    so = sin(x);
-    co = cos(x);
-    return;
-  }
   const double n = __builtin_rint(x * 0.63661977236758138);
   double r = __builtin_fma(-n, 1.5707963267948966, x);
   r = __builtin_fma(-n, 6.123233995736766e-17, r);
   r = __builtin_fma(-n, -1.4973849048591698e-33, r);
+  r = (__builtin_fabs(x) < 1125899906842624.0) ? r : __builtin_nan("");
   const double z = r * r;
   double ps = __builtin_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
   ps = __builtin_fma(z, ps, 2.75573137070700676789e-06);
@@ -121,7 +119,7 @@ DI void spec_sincos(double x, double& so, double& co) {
   pc = __builtin_fma(z, pc, -1.38888888888741095749e-03);
   pc = __builtin_fma(z, pc, 4.16666666666666019037e-02);
   pc = __builtin_fma(z * z, pc, __builtin_fma(z, -0.5, 1.0));
-  const int q = (int)n;
+  const int q = (int)__builtin_fma(-4.0, __builtin_rint(n * 0.25), n);  // n mod 4 in [-2, 2]
   const double s = (q & 1) ? pc : ps, c = (q & 1) ? ps : pc;
   so = (q & 2) ? -s : s;
   co = ((q + 1) & 2) ? -c : c;
@@ -152,11 +150,24 @@ DI void spec_sincos(double x, double& so, double& co) {
 #define BRBD_LAUNDER() do { } while (0)
 #define BRBD_CAT2(a, b) a##b
 #define BRBD_CAT(a, b) BRBD_CAT2(a, b)
+#ifdef BRBD_SPEC_TRACE
+// profiling build (tools/cg_variant.sh EXTRA=-DBRBD_SPEC_TRACE): wave 0 stamps the cycle counter at
+// every visit boundary into the buffer the host passes in A.prog3 (BRBD_TRACE=1 dumps it)
+#define VISIT_END()                                                                                  \
+  do {                                                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                               \
+    if (blockIdx.x == 0 && lane == 0 && A.prog3)                                                     \
+      reinterpret_cast<long long*>(const_cast<Op*>(A.prog3))[trace_ix] = __builtin_readcyclecounter(); \
+    ++trace_ix;                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                               \
+  } while (0)
+#else
 #define VISIT_END()                                                                                  \
   do {                                                                                               \
     __builtin_amdgcn_sched_barrier(0);                                                               \
     BRBD_LAUNDER();                                                                                  \
   } while (0)
+#endif
 
 // everything before the body: one tile of 64 instances per workgroup
 #define BRBD_SPEC_PROLOGUE(LDS_PAIRS)                                                                \
@@ -168,7 +179,8 @@ DI void spec_sincos(double x, double& so, double& co) {
   const unsigned wsoff = blockIdx.x * (unsigned)(A.ws_stride * 8) + (unsigned)lane * 16u;            \
   const unsigned ldq8 = (unsigned)A.ldq * 8u, ldv8 = (unsigned)A.ldv * 8u, ldx8 = (unsigned)A.lda * 8u; \
   const unsigned ldo8 = (unsigned)A.ldout * 8u, ldo28 = (unsigned)A.ldout2 * 8u;                     \
-  (void)lds2; (void)wsr; (void)wsoff;
+  int trace_ix = 0;                                                                                  \
+  (void)lds2; (void)wsr; (void)wsoff; (void)trace_ix;
 
 #define BRBD_SPEC_TILE(LAYOUT)                                                                       \
   int64_t inst = tile * WAVE + lane;                                                                 \

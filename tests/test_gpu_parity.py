@@ -386,8 +386,9 @@ def test_compiled_kernels_armature_and_gravity_change_selection():
     pool.release()
 
 
-def test_compiled_kernels_huge_angles():
-    """|q| >= 1e9 takes the library path of spec_sincos; moderate angles the Cody-Waite path."""
+def test_compiled_kernels_large_angles():
+    """spec_sincos is branch-free and exact to ~1 ulp for |q| < 2^50; beyond that it returns NaN by
+    design, while the table-driven kernels follow the library path like the reference."""
     model = S.arm7()
     pool = parallel.ModelPool(model, 1)
     O = oracle.Oracle(model)
@@ -396,6 +397,11 @@ def test_compiled_kernels_huge_angles():
     q[1, 16:32] *= 3.0e9
     q[2, 32:48] = -7.0e12
     assert rel_err_cols(parallel.rneaInParallel(1, pool, q, v, a), O.rnea(q, v, a)).max() < 1e-9
-    J, _ = parallel.computeJointJacobians(pool, q), None
-    assert np.abs(J - O.fk_jacobians(q)[0]).max() < 1e-9
+    assert np.abs(parallel.computeJointJacobians(pool, q) - O.fk_jacobians(q)[0]).max() < 1e-9
+    q[3, 48:] = 3.0e17
+    tau = parallel.rneaInParallel(1, pool, q, v, a)
+    assert np.isnan(tau[:, 48:]).any() and not np.isnan(tau[:, :48]).any()
+    pool.device_model(0).use_compiled(False)
+    tau = parallel.rneaInParallel(1, pool, q, v, a)
+    assert rel_err_cols(tau, O.rnea(q, v, a)).max() < 1e-9
     pool.release()

@@ -1,0 +1,14 @@
+import sys, numpy as np, torch
+sys.path.insert(0, '.')
+from pinocchio_amd import parallel, sample_models as S
+m = S.build(sys.argv[1] if len(sys.argv) > 1 else 'simple_humanoid')
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
+rng = np.random.default_rng(0)
+q = torch.from_numpy(np.ascontiguousarray(m.random_configuration(rng, B))).cuda()
+v = torch.from_numpy(rng.uniform(-1, 1, (m.nv, B))).cuda()
+a = torch.from_numpy(rng.uniform(-1, 1, (m.nv, B))).cuda()
+pool = parallel.ModelPool(m, 1)
+for _ in range(3):
+    tau = parallel.rneaInParallel(1, pool, q, v, a)
+    ddq = parallel.abaInParallel(1, pool, q, v, tau)
+torch.cuda.synchronize()

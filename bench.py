@@ -169,8 +169,17 @@ def main():
                     traffic = json.load(f).get("aba_kernel_bytes_per_launch")
             except Exception:
                 traffic = None
-        # algorithmic flops per eval (SURVEY 8d pre-estimates; counted values in DESIGN.md)
+        # algorithmic flops per eval (SURVEY 8d pre-estimates); what the kernels execute is in
+        # profiles/pmc_traffic.json (PMC: SQ_INSTS_VALU_{FMA,ADD,MUL}_F64, FMA = 2)
         flops = {"rnea": 8.5e3, "aba": 18.5e3}
+        executed = None
+        try:
+            with open(tj) as f:
+                executed = json.load(f).get("executed_flops_per_eval")
+        except Exception:
+            executed = None
+        variant = dm.compiled_kernels()
+        kname = (f"brbd::spec_{variant}::k_aba<1, 1>" if variant else "brbd::aba_kernel<1>")
         out = {
             "metric": "ABA/RNEA evals/sec, humanoid fp64 batch 65536",
             "value": 2 * B * args.steps * world / elapsed,
@@ -194,19 +203,21 @@ def main():
                 "aba_evals_per_s_kernel": B / (avg_a * 1e-3) if avg_a > 0 else None,
                 "instance_major_evals_per_s": im_rate,
                 "max_rel_err_aba_of_rnea": err,
+                "kernels": (f"model-compiled ({variant})" if variant else "table-driven"),
                 "parallelism": f"dp{world} (independent slices, no collective)",
             },
             "roofline": {
-                "bound": "hbm", "kernel": "aba_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "bound": "hbm", "kernel": kname, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": bytes_per_eval * B,
             },
             "roofline_fp64": {
-                "kernel": "aba_kernel", "achieved": flops["aba"] * B / (avg_a * 1e-3) / 1e12 if avg_a > 0 else None,
+                "kernel": kname, "achieved": flops["aba"] * B / (avg_a * 1e-3) / 1e12 if avg_a > 0 else None,
                 "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": (flops["aba"] * B / (avg_a * 1e-3) / 1e12 / FP64_PEAK_TFLOPS) if avg_a > 0 else None,
                 "rnea_achieved": flops["rnea"] * B / (avg_r * 1e-3) / 1e12 if avg_r > 0 else None,
                 "algorithmic_flops_per_eval": flops,
+                "executed_flops_per_eval": executed,
             },
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -98,11 +98,41 @@ def sym6_full(Ia: List[V]) -> List[List[V]]:
     return [[Ia[A.sidx(i, j)] for j in range(6)] for i in range(6)]
 
 
+# Tails.  A tail is a chain of up to TAIL joints that ends in a leaf.  Pass 2 does NOT keep the
+# hand-off records of tail joints; pass 3, arriving at the head of a tail with the parent's state,
+# walks down the tail, re-runs its backward visits (they depend on nothing outside the tail) and
+# only then sweeps down again for the accelerations.  Re-running a backward visit costs ~300
+# instructions (1 200 cycles); carrying its 7 doubles through HBM costs as much bandwidth as two
+# input vectors, and the kernel is bound by that traffic.
+TAIL = int(os.environ.get("BRBD_CG_TAIL", "2"))
+
+
+def find_tails(mv: J.ModelView, limit: int):
+    """joint -> the tail (list, head first, leaf last) it heads."""
+    tails = {}
+    if limit <= 0:
+        return tails
+    for leaf in range(1, mv.n):
+        if mv.children[leaf] or mv.parents[leaf] == 0:
+            continue
+        chain = [leaf]
+        while len(chain) < limit:
+            p = mv.parents[chain[-1]]
+            if p == 0 or mv.parents[p] == 0 or len(mv.children[p]) != 1:
+                break
+            chain.append(p)
+        chain.reverse()
+        tails[chain[0]] = chain
+    return tails
+
+
 def generate(mv: J.ModelView, e: Emitter) -> Emitter:
     g = None
     scpark = {}   # joint -> Park (s, c)
     hand = {}     # joint -> Park UDinv (6 nv) + Dinv u (nv)
     contrib = {}  # joint -> Park of the sum of the finished children's (Ia 21, of 6)
+    tails = find_tails(mv, TAIL)
+    in_tail = {j for ch in tails.values() for j in ch}
 
     def compose(p, Rp, tp, Rl, tl):
         if p == 0:  # aba.hxx:119-122
@@ -117,42 +147,43 @@ def generate(mv: J.ModelView, e: Emitter) -> Emitter:
         of = A.force_cross(e, ov, A.inertia_mul(e, m, cw, Iw, ov))
         return Ia, of
 
-    def backward(i, R, t, ov, Jc, ovJ, Ia, of):
-        """aba.hxx:153-193 for joint i standing at (R, t, ov).  Returns the root's acceleration
-        (parent == universe) or None."""
-        p = mv.parents[i]
+    def backward_root(i, R, t, Jc, Ia, of):
+        """Joint attached to the universe: a_gf[0] = -gravity is known, solve at once."""
         nv, iv = mv.nv(i), mv.idx_v[i]
         tau = [e.inp("X", iv + k) for k in range(nv)]
         arm = [mv.c(e, i, "arm", iv + k) for k in range(nv)]
-        if p == 0:
-            a0 = [-g[0], -g[1], -g[2], ZERO, ZERO, ZERO]  # aba.hxx:261
-            if mv.jtype[i] == M.JOINT_FREEFLYER and all(x.is_zero() for x in arm):
-                fw = A.act_force(e, R, t, tau)
-                rhs = A.vsub(e, fw, of)
-                a = chol_solve(e, chol_factor(e, sym6_full(Ia)), rhs)
-                dd = A.actinv_motion(e, R, t, A.vsub(e, a, a0))
-                for k in range(6):
-                    e.out(iv + k, dd[k])
-                return a
-            U = [A.sym6_mulvec(e, Ia, Jc[k]) for k in range(nv)]
-            x = [e.sub(e.sub(tau[k], A.dot6(e, Jc[k], of)), A.dot6(e, U[k], a0)) for k in range(nv)]
-            D = [[ZERO] * nv for _ in range(nv)]
-            for r in range(nv):
-                for c in range(r, nv):
-                    d = A.dot6(e, Jc[r], U[c])
-                    D[r][c] = D[c][r] = e.add(d, arm[r]) if r == c else d
-            if nv == 1:
-                dd = [e.mul(x[0], e.rcp(D[0][0]))]
-            else:
-                dd = chol_solve(e, chol_factor(e, D), x)
-            a = a0
-            for k in range(nv):
+        a0 = [-g[0], -g[1], -g[2], ZERO, ZERO, ZERO]  # aba.hxx:261
+        if mv.jtype[i] == M.JOINT_FREEFLYER and all(x.is_zero() for x in arm):
+            fw = A.act_force(e, R, t, tau)
+            rhs = A.vsub(e, fw, of)
+            a = chol_solve(e, chol_factor(e, sym6_full(Ia)), rhs)
+            dd = A.actinv_motion(e, R, t, A.vsub(e, a, a0))
+            for k in range(6):
                 e.out(iv + k, dd[k])
-                a = A.vaxpy(e, dd[k], Jc[k], a)
             return a
-        # bias acceleration ov_parent x ov_i (:129-132); ov_parent = ov - J vq
-        ovp = A.vsub(e, ov, ovJ)
-        bias = A.motion_cross(e, ovp, ov)
+        U = [A.sym6_mulvec(e, Ia, Jc[k]) for k in range(nv)]
+        x = [e.sub(e.sub(tau[k], A.dot6(e, Jc[k], of)), A.dot6(e, U[k], a0)) for k in range(nv)]
+        D = [[ZERO] * nv for _ in range(nv)]
+        for r in range(nv):
+            for c in range(r, nv):
+                d = A.dot6(e, Jc[r], U[c])
+                D[r][c] = D[c][r] = e.add(d, arm[r]) if r == c else d
+        if nv == 1:
+            dd = [e.mul(x[0], e.rcp(D[0][0]))]
+        else:
+            dd = chol_solve(e, chol_factor(e, D), x)
+        a = a0
+        for k in range(nv):
+            e.out(iv + k, dd[k])
+            a = A.vaxpy(e, dd[k], Jc[k], a)
+        return a
+
+    def backward_core(i, Jc, bias, Ia, of, want_parent=True):
+        """aba.hxx:153-193 for a joint with a moving parent.  Returns (UDinv columns, Dinv u,
+        contribution (Ia 21 + of 6) for the parent or None)."""
+        nv, iv = mv.nv(i), mv.idx_v[i]
+        tau = [e.inp("X", iv + k) for k in range(nv)]
+        arm = [mv.c(e, i, "arm", iv + k) for k in range(nv)]
         u = [e.sub(tau[k], A.dot6(e, Jc[k], of)) for k in range(nv)]  # :173
         U = [A.sym6_mulvec(e, Ia, Jc[k]) for k in range(nv)]          # :175
         D = [[ZERO] * nv for _ in range(nv)]
@@ -167,7 +198,8 @@ def generate(mv: J.ModelView, e: Emitter) -> Emitter:
         UD = [[e.dot([U[r][k] for r in range(nv)], [Dinv[r][c] for r in range(nv)]) for k in range(6)]
               for c in range(nv)]                                     # :182
         Dinvu = [e.dot(Dinv[r], u) for r in range(nv)]
-        hand[i] = e.park([x for col in UD for x in col] + Dinvu, "hand")
+        if not want_parent:
+            return UD, Dinvu, None
         Ia2 = list(Ia)
         for a_ in range(6):
             for b_ in range(a_, 6):
@@ -178,13 +210,7 @@ def generate(mv: J.ModelView, e: Emitter) -> Emitter:
         pa = A.sym6_mulvec(e, Ia2, bias, of)                          # :188
         for c in range(nv):
             pa = A.vaxpy(e, u[c], UD[c], pa)                          # :189
-        # :190-191  oYaba[parent] += Ia, of[parent] += of: one running accumulator per parent (the
-        # first finished child starts it, later ones add to it), consumed by the parent's backward visit
-        acc = Ia2 + pa
-        if p in contrib:
-            acc = A.vadd(e, e.unpark(contrib[p]), acc)
-        contrib[p] = e.park(acc, "stack")
-        return None
+        return UD, Dinvu, Ia2 + pa
 
     def step_back(R, t, ov, Rl, tl, ovJ):
         """kinematics of the parent from the child's: oMp = oMi * liMi^-1, ov_p = ov_i - J vq"""
@@ -192,10 +218,95 @@ def generate(mv: J.ModelView, e: Emitter) -> Emitter:
         tp = A.vsub(e, t, A.rot_vec(e, Rp, tl))
         return Rp, tp, A.vsub(e, ov, ovJ)
 
+    def kinematics(i, Rp, tp, ovp, sc=None):
+        """world placement, Jacobian columns, velocity of joint i from its parent's"""
+        p = mv.parents[i]
+        Rl, tl, sc = J.joint_transform(e, mv, i, sc=sc)
+        R, t = compose(p, Rp, tp, Rl, tl)
+        nv, iv = mv.nv(i), mv.idx_v[i]
+        Jc = [A.act_motion(e, R, t, col) for col in J.subspace(e, mv, i)]  # aba.hxx:124
+        vq = [e.inp("V", iv + k) for k in range(nv)]
+        ovJ = A.zeros(6)
+        for k in range(nv):
+            ovJ = A.vaxpy(e, vq[k], Jc[k], ovJ)                            # :126
+        ov = ovJ if p == 0 else A.vadd(e, ovp, ovJ)                        # :127-128
+        return R, t, ov, Jc, ovJ, Rl, tl, sc
+
+    def flat(R, t, *vecs):
+        out = [x for row in R for x in row] + list(t)
+        for v in vecs:
+            out += list(v)
+        return out
+
+    def pass3_joint(i, ap, bias, Jc, UD, Dinvu, leaf):
+        """:223-227  a_i = a_parent + bias; ddq = Dinv u - UDinv^T a_i; a_i += J ddq"""
+        nv, iv = mv.nv(i), mv.idx_v[i]
+        a = A.vadd(e, ap, bias)
+        dd = []
+        for k in range(nv):
+            d = e.sub(Dinvu[k], A.dot6(e, UD[k], a))
+            dd.append(d)
+            e.out(iv + k, d)
+        if not leaf:
+            for k in range(nv):
+                a = A.vaxpy(e, dd[k], Jc[k], a)
+        return a
+
+    def pass3_tail(chain, kin_parent):
+        """Pass 3 over a tail whose hand-off records were not kept: down (kinematics), up (the
+        backward visits again), down (accelerations)."""
+        n = len(chain)
+        keep = {}   # joint -> Park of R, t, ov, J, bias (needed by its backward visit and the sweep)
+        rec = {}    # joint -> Park of UDinv, Dinv u
+        state = None
+        for k, i in enumerate(chain):
+            leaf = k == n - 1
+            e.begin_visit("TAIL down %d%s" % (i, " + up (leaf)" if leaf else ""))
+            if k == 0:
+                vals = e.unpark(kin_parent)
+                Rp, tp, ovp = [vals[0:3], vals[3:6], vals[6:9]], vals[9:12], vals[12:18]
+                a_head = vals[18:24]
+            else:
+                Rp, tp, ovp = state
+            R, t, ov, Jc, ovJ, _, _, _ = kinematics(i, Rp, tp, ovp)
+            bias = A.motion_cross(e, ovp, ov)
+            state = (R, t, ov)
+            if leaf:
+                Ia, of = own_inertia(i, R, t, ov)
+                UD, Dinvu, up = backward_core(i, Jc, bias, Ia, of, want_parent=n > 1)
+                rec[i] = e.park([x for col in UD for x in col] + Dinvu + [x for col in Jc for x in col] + bias,
+                                "tail")
+                carry = up
+            else:
+                keep[i] = e.park(flat(R, t, ov) + [x for col in Jc for x in col] + bias, "tail")
+        for k in range(n - 2, -1, -1):
+            i = chain[k]
+            nv = mv.nv(i)
+            e.begin_visit("TAIL up %d" % i)
+            vals = e.unpark(keep[i])
+            R, t, ov = [vals[0:3], vals[3:6], vals[6:9]], vals[9:12], vals[12:18]
+            Jc = [vals[18 + 6 * c:24 + 6 * c] for c in range(nv)]
+            bias = vals[18 + 6 * nv:24 + 6 * nv]
+            Ia, of = own_inertia(i, R, t, ov)
+            Ia = A.vadd(e, Ia, carry[:21])
+            of = A.vadd(e, of, carry[21:])
+            UD, Dinvu, carry = backward_core(i, Jc, bias, Ia, of, want_parent=k > 0)
+            rec[i] = e.park([x for col in UD for x in col] + Dinvu + [x for col in Jc for x in col] + bias, "tail")
+        a = a_head
+        for k, i in enumerate(chain):
+            nv = mv.nv(i)
+            e.begin_visit("TAIL sweep %d" % i)
+            vals = e.unpark(rec[i])
+            UD = [vals[6 * c:6 * c + 6] for c in range(nv)]
+            Dinvu = vals[6 * nv:7 * nv]
+            Jc = [vals[7 * nv + 6 * c:7 * nv + 6 * c + 6] for c in range(nv)]
+            bias = vals[13 * nv:13 * nv + 6]
+            a = pass3_joint(i, a, bias, Jc, UD, Dinvu, k == n - 1)
+
     def pass3(root, Rr, tr, ovr, ar):
         """aba.hxx:207-232 over the subtree of `root` (whose own ddq is already written)."""
         # state of a joint for its children: Park of R (9), t (3), ov (6), a_gf (6)
-        kin = {root: e.park([x for row in Rr for x in row] + list(tr) + list(ovr) + list(ar), "stack")}
+        kin = {root: e.park(flat(Rr, tr, ovr, ar), "stack")}
         order = []
 
         def rec(i):
@@ -206,32 +317,23 @@ def generate(mv: J.ModelView, e: Emitter) -> Emitter:
         rec(root)
         for i in order:
             p = mv.parents[i]
+            if i in tails:
+                pass3_tail(tails[i], kin[p])
+                continue
+            if i in in_tail:
+                continue
             e.begin_visit("PASS3 %d" % i)
             vals = e.unpark(kin[p])
             Rp, tp, ovp, ap = [vals[0:3], vals[3:6], vals[6:9]], vals[9:12], vals[12:18], vals[18:24]
-            if i in scpark and not RECOMPUTE_SINCOS:
-                Rl, tl, _ = J.joint_transform(e, mv, i, sc=tuple(e.unpark(scpark[i])))
-            else:
-                Rl, tl, _ = J.joint_transform(e, mv, i)
-            R, t = compose(p, Rp, tp, Rl, tl)
-            nv, iv = mv.nv(i), mv.idx_v[i]
-            S = J.subspace(e, mv, i)
-            Jc = [A.act_motion(e, R, t, col) for col in S]
-            vq = [e.inp("V", iv + k) for k in range(nv)]
-            ov = ovp
-            for k in range(nv):
-                ov = A.vaxpy(e, vq[k], Jc[k], ov)
-            a = A.vadd(e, ap, A.motion_cross(e, ovp, ov))  # :223 with the bias of :129-132
+            sc = tuple(e.unpark(scpark[i])) if (i in scpark and not RECOMPUTE_SINCOS) else None
+            R, t, ov, Jc, _, _, _, _ = kinematics(i, Rp, tp, ovp, sc=sc)
+            bias = A.motion_cross(e, ovp, ov)  # the bias of :129-132
+            nv = mv.nv(i)
             h = e.unpark(hand[i])
-            dd = []
-            for k in range(nv):
-                d = e.sub(h[6 * nv + k], A.dot6(e, h[6 * k:6 * k + 6], a))  # :224-226
-                dd.append(d)
-                e.out(iv + k, d)
+            a = pass3_joint(i, ap, bias, Jc, [h[6 * k:6 * k + 6] for k in range(nv)], h[6 * nv:7 * nv],
+                            not mv.children[i])
             if mv.children[i]:
-                for k in range(nv):
-                    a = A.vaxpy(e, dd[k], Jc[k], a)  # :227
-                kin[i] = e.park([x for row in R for x in row] + list(t) + ov + a, "stack")
+                kin[i] = e.park(flat(R, t, ov, a), "stack")
 
     for root in sorted(mv.children[0], reverse=True):
         cur = None  # (R, t, ov) of the joint the walk stands on
@@ -243,20 +345,9 @@ def generate(mv: J.ModelView, e: Emitter) -> Emitter:
             e.begin_visit("FWD %d%s" % (i, " + BWD (leaf)" if leaf else ""))
             if g is None or p == 0:
                 g = mv.gravity(e)
-            Rl, tl, sc = J.joint_transform(e, mv, i)
-            if p == 0:
-                R, t = Rl, tl
-            else:
-                R, t = compose(p, cur[0], cur[1], Rl, tl)
-            nv, iv = mv.nv(i), mv.idx_v[i]
-            S = J.subspace(e, mv, i)
-            Jc = [A.act_motion(e, R, t, col) for col in S]  # aba.hxx:124
-            vq = [e.inp("V", iv + k) for k in range(nv)]
-            ovJ = A.zeros(6)
-            for k in range(nv):
-                ovJ = A.vaxpy(e, vq[k], Jc[k], ovJ)         # :126
-            ov = ovJ if p == 0 else A.vadd(e, cur[2], ovJ)  # :127-128
-            if sc is not None and p != 0 and not RECOMPUTE_SINCOS:
+            R, t, ov, Jc, ovJ, Rl, tl, sc = kinematics(i, cur[0] if cur else None, cur[1] if cur else None,
+                                                       cur[2] if cur else None)
+            if sc is not None and p != 0 and not RECOMPUTE_SINCOS and i not in in_tail:
                 scpark[i] = e.park(list(sc), "hand")
             elif sc is not None and not leaf:
                 scpark[i] = e.park(list(sc), "stack")
@@ -268,12 +359,10 @@ def generate(mv: J.ModelView, e: Emitter) -> Emitter:
                 if p == 0:
                     g = mv.gravity(e)
                 R, t, ov = cur
-                if i in scpark:
-                    Rl, tl, _ = J.joint_transform(e, mv, i, sc=tuple(e.unpark(scpark[i])))
-                else:
-                    Rl, tl, _ = J.joint_transform(e, mv, i)
-                S = J.subspace(e, mv, i)
-                Jc = [A.act_motion(e, R, t, col) for col in S]
+                sc = tuple(e.unpark(scpark[i])) if i in scpark else None
+                Rl, tl, _ = J.joint_transform(e, mv, i, sc=sc)
+                nv, iv = mv.nv(i), mv.idx_v[i]
+                Jc = [A.act_motion(e, R, t, col) for col in J.subspace(e, mv, i)]
                 vq = [e.inp("V", iv + k) for k in range(nv)]
                 ovJ = A.zeros(6)
                 for k in range(nv):
@@ -283,9 +372,18 @@ def generate(mv: J.ModelView, e: Emitter) -> Emitter:
                 vals = e.unpark(contrib.pop(i))
                 Ia = A.vadd(e, Ia, vals[:21])
                 of = A.vadd(e, of, vals[21:])
-            a_root = backward(i, R, t, ov, Jc, ovJ, Ia, of)
             if p == 0:
-                return a_root
+                return backward_root(i, R, t, Jc, Ia, of)
+            # bias acceleration ov_parent x ov_i (:129-132); ov_parent = ov - J vq
+            bias = A.motion_cross(e, A.vsub(e, ov, ovJ), ov)
+            UD, Dinvu, acc = backward_core(i, Jc, bias, Ia, of)
+            if i not in in_tail:
+                hand[i] = e.park([x for col in UD for x in col] + Dinvu, "hand")
+            # :190-191  oYaba[parent] += Ia, of[parent] += of: one running accumulator per parent (the
+            # first finished child starts it, later ones add to it), consumed by the parent's backward
+            if p in contrib:
+                acc = A.vadd(e, e.unpark(contrib[p]), acc)
+            contrib[p] = e.park(acc, "stack")
             cur = step_back(R, t, ov, Rl, tl, ovJ)
             return None
 

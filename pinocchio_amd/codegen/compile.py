@@ -27,7 +27,7 @@ ALGOS = {"rnea": rnea.generate, "aba": aba.generate, "fkjac": fkjac.generate}
 # storage budgets (doubles per lane) of the park planner, per algorithm:
 # (registers for short-lived parks, LDS, registers for long-lived parks)
 # LDS: 160 KiB per CU, 4 resident waves of 64 lanes at one wave per SIMD -> 80 doubles per lane
-BUDGETS = {"rnea": (40, 80, 0), "aba": (16, 80, 100), "fkjac": (36, 80, 0)}
+BUDGETS = {"rnea": (40, 80, 0), "aba": (16, 80, 100, 64), "fkjac": (36, 80, 0)}
 for _a in list(BUDGETS):  # experiment hook: BRBD_CG_ABA="64,80"
     _v = os.environ.get("BRBD_CG_" + _a.upper())
     if _v:
@@ -43,11 +43,12 @@ class Kernel:
 def build_kernel(mv: joints.ModelView, algo: str, reg_budget: Optional[int] = None,
                  lds_budget: Optional[int] = None) -> Kernel:
     gen = ALGOS[algo]
-    rb, lb, rl = BUDGETS[algo]
+    rb, lb, rl = BUDGETS[algo][:3]
+    rt = BUDGETS[algo][3] if len(BUDGETS[algo]) > 3 else 64
     rb = rb if reg_budget is None else reg_budget
     lb = lb if lds_budget is None else lds_budget
     dry = gen(mv, Emitter())
-    plan, lds, glb = plan_storage(dry.parks, rb, lb, rl)
+    plan, lds, glb = plan_storage(dry.parks, rb, lb, rl, rt)
     e = gen(mv, Emitter(plan))
     return Kernel(algo, e.text(), list(e.const_list), lds, glb, dict(e.stats), len(e.visits))
 

@@ -386,7 +386,7 @@ class Emitter:
         return "\n".join(lines) + "\n"
 
 
-def plan_storage(parks: Sequence[Park], reg_short: int, lds_budget: int, reg_long: int = 0):
+def plan_storage(parks: Sequence[Park], reg_short: int, lds_budget: int, reg_long: int = 0, reg_tail: int = 64):
     """Assign every park a storage class: ("reg" | "lds" | "glb", first slot).
 
     * A park consumed by the very next visit stays in registers (chains hand state over for free).
@@ -424,7 +424,9 @@ def plan_storage(parks: Sequence[Park], reg_short: int, lds_budget: int, reg_lon
         # register-parked doubles live at any time during pk's lifetime (upper bound: all overlapping)
         return sum(size_of(p) for p in placed if p.start < pk.end and pk.start < p.end)
 
-    for hint, budget in (("stack", reg_short), ("hand", reg_long)):
+    # ("tail": what ABA's pass 3 keeps while it re-runs the backward visits of a tail; short-lived,
+    # at a time when the visits are light on registers)
+    for hint, budget in (("stack", reg_short), ("tail", reg_tail), ("hand", reg_long)):
         placed = []
         for pk in sorted((p for p in parks if p.hint == hint), key=lambda p: (p.start, p.pid)):
             size = size_of(pk)

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""The other BASELINE.json configs on one GPU (device-resident BATCH_MAJOR), kernel time from the
+library's hipEvents: [1] arm7 FK + Jacobians B=1M, [3] talos-class ABA B=1M (one GPU's slice of the
+8M), [4] quadruped RNEA derivatives B=262144.  Prints one JSON line per config."""
+import json, sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from pinocchio_amd import capi, parallel, sample_models as S
+
+def inputs(m, B):
+    rng = np.random.default_rng(0)
+    q = torch.from_numpy(np.ascontiguousarray(m.random_configuration(rng, B))).cuda()
+    v = torch.from_numpy(rng.uniform(-1, 1, (m.nv, B))).cuda()
+    a = torch.from_numpy(rng.uniform(-1, 1, (m.nv, B))).cuda()
+    return q, v, a
+
+def timed(dm, algo, fn, reps):
+    for _ in range(2): fn()
+    torch.cuda.synchronize(); dm.kernel_time(algo); dm.set_timing(True)
+    for _ in range(reps): fn()
+    torch.cuda.synchronize(); dm.set_timing(False)
+    n, ms = dm.kernel_time(algo)
+    return ms / max(n, 1) * 1e-3 * (n / reps)   # seconds per call (chunked launches summed)
+
+which = sys.argv[1:] or ["fkjac", "aba", "rnea", "deriv"]
+if "fkjac" in which:
+    m = S.arm7(); B = 1 << 20; pool = parallel.ModelPool(m, 1); dm = pool.device_model(0)
+    q, _, _ = inputs(m, B)
+    t = timed(dm, capi.ALGO_FK_JAC, lambda: parallel.computeJointJacobians(pool, q), 10)
+    byts = (m.nq + 6 * m.nv) * 8 * B
+    print(json.dumps({"config": "arm7 FK+J (J only) B=1048576", "kernels": dm.compiled_kernels(), "s_per_call": t,
+                      "evals_per_s": B / t, "GBps_algorithmic": byts / t / 1e9}))
+    t = timed(dm, capi.ALGO_FK_JAC, lambda: parallel.computeJointJacobians(pool, q, want_oMi=True), 10)
+    byts = (m.nq + 6 * m.nv + 12 * m.njoints) * 8 * B
+    print(json.dumps({"config": "arm7 FK+J (J + oMi) B=1048576", "s_per_call": t, "evals_per_s": B / t,
+                      "GBps_algorithmic": byts / t / 1e9}))
+    pool.release()
+for name in ("aba", "rnea"):
+    if name in which:
+        m = S.talos_like(); B = 1 << 20; pool = parallel.ModelPool(m, 1); dm = pool.device_model(0)
+        q, v, a = inputs(m, B)
+        out = torch.empty_like(a)
+        f = (lambda: parallel.abaInParallel(1, pool, q, v, a, out)) if name == "aba" else (lambda: parallel.rneaInParallel(1, pool, q, v, a, out))
+        t = timed(dm, capi.ALGO_ABA if name == "aba" else capi.ALGO_RNEA, f, 5)
+        print(json.dumps({"config": f"talos_like {name.upper()} B=1048576", "kernels": dm.compiled_kernels(), "s_per_call": t,
+                          "evals_per_s": B / t, "GBps_algorithmic": (m.nq + 3 * m.nv) * 8 * B / t / 1e9}))
+        pool.release()
+if "deriv" in which:
+    m = S.quadruped(); B = 1 << 18; pool = parallel.ModelPool(m, 1); dm = pool.device_model(0)
+    q, v, a = inputs(m, B)
+    t = timed(dm, capi.ALGO_RNEA_DERIV, lambda: parallel.computeRNEADerivatives(pool, q, v, a), 5)
+    byts = ((m.nq + 2 * m.nv) + 3 * m.nv * m.nv) * 8 * B
+    print(json.dumps({"config": "quadruped RNEA derivatives B=262144", "s_per_call": t, "evals_per_s": B / t,
+                      "GBps_algorithmic": byts / t / 1e9}))
+    pool.release()

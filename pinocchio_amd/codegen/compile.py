@@ -19,19 +19,32 @@ from typing import Dict, Optional
 import numpy as np
 
 from .. import model as M
-from . import aba, fkjac, joints, rnea
-from .emit import Emitter, plan_storage
+from . import aba, deriv, fkjac, joints, rnea
+from .emit import AHEAD, Emitter, plan_storage
 
-ALGOS = {"rnea": rnea.generate, "aba": aba.generate, "fkjac": fkjac.generate}
+ALGOS = {"rnea": rnea.generate, "aba": aba.generate, "fkjac": fkjac.generate, "deriv": deriv.generate}
 
 # storage budgets (doubles per lane) of the park planner, per algorithm:
 # (registers for short-lived parks, LDS, registers for long-lived parks)
 # LDS: 160 KiB per CU, 4 resident waves of 64 lanes at one wave per SIMD -> 80 doubles per lane
-BUDGETS = {"rnea": (40, 80, 0), "aba": (16, 80, 100, 64), "fkjac": (36, 80, 0)}
+BUDGETS = {"rnea": (40, 80, 0), "aba": (16, 80, 100, 64), "fkjac": (36, 80, 0), "deriv": (40, 80, 0, 64)}
 for _a in list(BUDGETS):  # experiment hook: BRBD_CG_ABA="64,80"
     _v = os.environ.get("BRBD_CG_" + _a.upper())
     if _v:
         BUDGETS[_a] = tuple(int(x) for x in _v.split(","))
+
+
+# prefetch distances that differ from emit.AHEAD (the derivative kernel's pair visits consume a
+# parked value every other statement: a long distance keeps hundreds of them in flight)
+AHEAD_ALGO = {"deriv": {"glb": 120, "in": 200}}
+for _a in list(ALGOS):  # experiment hook: BRBD_CG_AHEAD_DERIV="glb=200,in=100"
+    for _kv in os.environ.get("BRBD_CG_AHEAD_" + _a.upper(), "").split(","):
+        if "=" in _kv:
+            AHEAD_ALGO.setdefault(_a, {})[_kv.split("=")[0]] = int(_kv.split("=")[1])
+
+
+# algorithms whose early loads are placed at statement granularity (emit.Emitter.text, ``fine``)
+FINE = set(os.environ.get("BRBD_CG_FINE", "deriv").split(","))
 
 
 class Kernel:
@@ -50,7 +63,7 @@ def build_kernel(mv: joints.ModelView, algo: str, reg_budget: Optional[int] = No
     dry = gen(mv, Emitter())
     plan, lds, glb = plan_storage(dry.parks, rb, lb, rl, rt)
     e = gen(mv, Emitter(plan))
-    return Kernel(algo, e.text(), list(e.const_list), lds, glb, dict(e.stats), len(e.visits))
+    return Kernel(algo, e.text(dict(AHEAD, **AHEAD_ALGO.get(algo, {})), algo in FINE), list(e.const_list), lds, glb, dict(e.stats), len(e.visits))
 
 
 def pack_constants(mv: joints.ModelView, const_list) -> np.ndarray:
@@ -67,6 +80,7 @@ _CPU_SHELL = r"""
 #define OUT(k, val) out[k] = (val)
 #define OUT2(k, val) out2[k] = (val)
 #define OUT3(k, val) out3[k] = (val)
+#define OUT4(k, val) out4[k] = (val)
 #define SINCOS(a, s, c) sincos(a, &s, &c)
 #define RSQRT(a) (1.0 / sqrt(a))
 #define RCP(a) (1.0 / (a))
@@ -78,17 +92,17 @@ _CPU_SHELL = r"""
 #define VISIT_END() do { } while (0)
 #define OPAQUE(x) do { } while (0)
 static void one(const double* ct, const double* q, const double* v, const double* x, double* out,
-                double* out2, double* out3, double* lds, double* glb) {
-  (void)ct; (void)q; (void)v; (void)x; (void)out; (void)out2; (void)out3; (void)lds; (void)glb;
+                double* out2, double* out3, double* out4, double* lds, double* glb) {
+  (void)ct; (void)q; (void)v; (void)x; (void)out; (void)out2; (void)out3; (void)out4; (void)lds; (void)glb;
 #include "BODY"
 }
 void spec_batch(const double* ct, long B, const double* q, long ldq, const double* v, long ldv,
                 const double* x, long ldx, double* out, long ldo, double* out2, long ldo2, double* out3,
-                long ldo3) {
+                long ldo3, double* out4, long ldo4) {
   double lds[LDS_N + 2], glb[GLB_N + 2];
   for (long b = 0; b < B; ++b)
     one(ct, q + b * ldq, v ? v + b * ldv : 0, x ? x + b * ldx : 0, out + b * ldo, out2 ? out2 + b * ldo2 : 0,
-        out3 ? out3 + b * ldo3 : 0, lds, glb);
+        out3 ? out3 + b * ldo3 : 0, out4 ? out4 + b * ldo4 : 0, lds, glb);
 }
 """
 
@@ -112,9 +126,10 @@ class CpuKernel:
         subprocess.check_call(["gcc", "-O1", "-ffp-contract=off", "-shared", "-fPIC", "-o", so, src, "-lm"])
         self.lib = ctypes.CDLL(so)
         dp, l = ctypes.POINTER(ctypes.c_double), ctypes.c_long
-        self.lib.spec_batch.argtypes = [dp, l, dp, l, dp, l, dp, l, dp, l, dp, l, dp, l]
+        self.lib.spec_batch.argtypes = [dp, l, dp, l, dp, l, dp, l, dp, l, dp, l, dp, l, dp, l]
 
     def run(self, q, v=None, x=None, out_rows=(0, 0, 0)):
+        out_rows = tuple(out_rows) + (0,) * (4 - len(out_rows))
         def P(a):
             return None if a is None else a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
 
@@ -125,7 +140,7 @@ class CpuKernel:
         outs = [np.zeros((r, B), order="F") if r else None for r in out_rows]
         self.lib.spec_batch(P(self.ct), B, P(q), q.shape[0], P(v), 0 if v is None else v.shape[0], P(x),
                             0 if x is None else x.shape[0], P(outs[0]), out_rows[0], P(outs[1]), out_rows[1],
-                            P(outs[2]), out_rows[2])
+                            P(outs[2]), out_rows[2], P(outs[3]), out_rows[3])
         return outs
 
 

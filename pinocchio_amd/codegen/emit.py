@@ -358,16 +358,41 @@ class Emitter:
         return out
 
     # ---- output ----------------------------------------------------------------------------------
-    def text(self, ahead: Optional[Dict[str, int]] = None) -> str:
+    def text(self, ahead: Optional[Dict[str, int]] = None, fine: bool = False) -> str:
         """Concatenate the visits.  An early load of visit k is issued at the start of the latest
         visit that lies at least ahead[kind] STATEMENTS (~ instructions, 4 cycles each with one
         wave per SIMD) before visit k, but not before its ``earliest`` visit.  With a single wave per
         SIMD nothing else hides memory latency: HBM wants thousands of cycles of distance, LDS and
         the scalar cache a few hundred.  (Visits differ in length by 20x, so a distance counted in
-        visits either starves the long ones or floods the registers in the short ones.)"""
+        visits either starves the long ones or floods the registers in the short ones.)
+        ``fine``: place each early load exactly ahead[kind] statements before its visit, inside the
+        body of the earlier visit, instead of bunching them at visit starts (lower register peaks
+        when many short visits each consume a parked block)."""
         ahead = ahead or AHEAD
         n = len(self.visits)
         size = [len(v.body) for v in self.visits]
+        if fine:
+            start = [0] * (n + 1)
+            for k in range(n):
+                start[k + 1] = start[k] + size[k]
+            ins: Dict[int, List[str]] = {}
+            for k in range(n):
+                for line, kind, earliest in self.visits[k].pre:
+                    pos = max(start[min(max(earliest, 0), k)], start[k] - ahead.get(kind, 0))
+                    ins.setdefault(pos, []).append(line)
+            lines = []
+            for k in range(n):
+                lines += ins.get(start[k], []) if size[k] else []
+                lines.append("/* ---- visit %d: %s ---- */" % (k, self.visits[k].label))
+                for j, st in enumerate(self.visits[k].body):
+                    if j > 0:
+                        lines += ins.get(start[k] + j, [])
+                    lines.append(st)
+                if not size[k]:  # (an empty visit shares its position with the next one)
+                    pass
+                lines.append("VISIT_END();")
+            assert not ins.get(start[n]), "early load after the last statement"
+            return "\n".join(lines) + "\n"
         early: List[List[str]] = [[] for _ in range(n)]
         for k in range(n):
             for line, kind, earliest in self.visits[k].pre:

@@ -63,7 +63,7 @@ struct brbd_model {
   int max_waves_spec[4] = {0, 0, 0, 0};
   // model-compiled kernels (brbd_spec.hpp), when the model's signature is registered
   const SpecEntry* spec = nullptr;
-  double* d_ct[3] = {nullptr, nullptr, nullptr};  // packed constant table per algorithm
+  double* d_ct[4] = {nullptr, nullptr, nullptr, nullptr};  // packed constant table per algorithm
   bool use_spec = true;  // BRBD_DISABLE_COMPILED=1 or brbd_model_use_compiled(m, 0): table-driven kernels
   bool use_lds = true;
   bool timing = false;
@@ -224,6 +224,7 @@ int launch_algo(brbd_model* m, int algo, KArgs& A, int layout, hipStream_t strea
     case BRBD_ALGO_RNEA: per_lane = F.stack_rnea(); break;
     case BRBD_ALGO_ABA: per_lane = F.ws_aba(); break;
     case BRBD_ALGO_FK_JAC: per_lane = F.ws_fkjac(); break;
+    case BRBD_ALGO_RNEA_DERIV: per_lane = 1; break;  // (only reached when a compiled kernel exists)
     default: return fail(BRBD_ERR_INVALID_ARGUMENT, "unknown algorithm");
   }
   // model-compiled kernel?  (BATCH_MAJOR addresses elements with 32-bit byte offsets)
@@ -233,11 +234,13 @@ int launch_algo(brbd_model* m, int algo, KArgs& A, int layout, hipStream_t strea
     if (algo == BRBD_ALGO_FK_JAC) variant = (A.out ? 1 : 0) | (A.out2 ? 2 : 0);
     else variant = 0;
     // buffer ranges: every matrix must span less than 4 GiB (32-bit byte offsets)
-    const int64_t dofs[5] = {F.nq, F.nv, F.nv, algo == BRBD_ALGO_FK_JAC ? 6 * (int64_t)F.nv : F.nv,
-                             12 * (int64_t)F.njoints};
-    const void* ptrs[5] = {A.q, A.v, A.a, A.out, A.out2};
-    const int64_t lds_[5] = {A.ldq, A.ldv, A.lda, A.ldout, A.ldout2};
-    for (int k = 0; k < 5 && sk; ++k) {
+    const int64_t nn = (int64_t)F.nv * F.nv;
+    const bool der = algo == BRBD_ALGO_RNEA_DERIV;
+    const int64_t dofs[7] = {F.nq, F.nv, F.nv, der ? nn : (algo == BRBD_ALGO_FK_JAC ? 6 * (int64_t)F.nv : F.nv),
+                             der ? nn : 12 * (int64_t)F.njoints, nn, F.nv};
+    const void* ptrs[7] = {A.q, A.v, A.a, A.out, A.out2, A.out3, A.out4};
+    const int64_t lds_[7] = {A.ldq, A.ldv, A.lda, A.ldout, A.ldout2, A.ldout3, A.ldout4};
+    for (int k = 0; k < 7 && sk; ++k) {
       A.nb[k] = 0;
       if (!ptrs[k]) continue;
       const double span = 8.0 * (layout == BRBD_BATCH_MAJOR ? (double)lds_[k] * (double)dofs[k]
@@ -247,6 +250,7 @@ int launch_algo(brbd_model* m, int algo, KArgs& A, int layout, hipStream_t strea
     }
     if (sk && !sk->fn[layout][variant]) sk = nullptr;
   }
+  if (algo == BRBD_ALGO_RNEA_DERIV && !sk) return 1;  // caller falls back to the table-driven kernel
   const bool stat = sk != nullptr;
   SpecFn sfn = stat ? sk->fn[layout][variant] : nullptr;
   int& mw = stat ? m->max_waves_spec[algo] : m->max_waves[algo];
@@ -408,7 +412,7 @@ int brbd_model_create(const brbd_model_desc* desc, int device, brbd_model** out)
     for (int pass = 0; pass < 2 && !m->spec; ++pass)
       for (int k = 0; k < spec_entry_count && !m->spec; ++k)
         if ((pass == 0 ? exact : dense) == spec_entries[k]->signature) m->spec = spec_entries[k];
-    for (int a = 0; m->spec && a < 3 && e == hipSuccess; ++a) {
+    for (int a = 0; m->spec && a < 4 && e == hipSuccess; ++a) {
       const std::vector<double> ct = pack_constants(m->flat, m->spec->algo[a]);
       e = upload((void**)&m->d_ct[a], ct.data(), ct.size() * sizeof(double));
     }
@@ -625,6 +629,15 @@ int brbd_rnea_derivatives(brbd_model* m, int64_t B, const double* q, int64_t ldq
                  double* pda, double* pt) -> int {
     D.q = dq_; D.ldq = ldq; D.v = dv_; D.ldv = ldv; D.a = da_; D.lda = lda;
     D.dq = pdq; D.lddq = lddq; D.dv = pdv; D.lddv = lddv; D.da = pda; D.ldda = ldda; D.tau = pt; D.ldtau = ldtau;
+    if (m->spec && m->use_spec) {  // model-compiled kernel (codegen/deriv.py), when registered
+      KArgs A{};
+      fill_common(m, A, B);
+      A.q = dq_; A.ldq = ldq; A.v = dv_; A.ldv = ldv; A.a = da_; A.lda = lda;
+      A.out = pdq; A.ldout = lddq; A.out2 = pdv; A.ldout2 = lddv; A.out3 = pda; A.ldout3 = ldda;
+      A.out4 = pt; A.ldout4 = ldtau;
+      const int r = launch_algo(m, BRBD_ALGO_RNEA_DERIV, A, layout, s);
+      if (r <= 0) return r;  // 1 = no compiled kernel applies
+    }
     if (m->max_waves[BRBD_ALGO_RNEA_DERIV] == 0)
       m->max_waves[BRBD_ALGO_RNEA_DERIV] = resident_waves(m, rnea_deriv_kernel<1>, WAVE);
     const int64_t grid = D.ntiles < m->max_waves[3] ? D.ntiles : m->max_waves[3];

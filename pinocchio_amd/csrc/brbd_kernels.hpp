@@ -48,7 +48,9 @@ struct KArgs {
   double* out2; int64_t ldout2;  // FKJ: oMi
   const double* ctab;            // model-compiled kernels (brbd_spec.hpp): packed constant table
   int64_t tile0;                 //   first tile of this launch (the host launches in chunks)
-  uint32_t nb[5];                //   bytes spanned by q, v, a/tau, out, out2 (buffer ranges; 0 = absent)
+  double* out3; int64_t ldout3;  //   RNEA derivatives: dtau/da
+  double* out4; int64_t ldout4;  //   RNEA derivatives: tau
+  uint32_t nb[7];                //   bytes spanned by q, v, a/tau, out, out2, out3, out4 (0 = absent)
   uint32_t ws_bytes;             //   bytes of the global park area of this launch
 };
 

@@ -33,7 +33,7 @@ enum : int { SF_R = 0, SF_T, SF_M, SF_C, SF_I, SF_ARM, SF_AXIS, SF_G };
 struct SpecEntry {
   const char* name;
   const char* signature;  // tree + joint kinds + 0/1/-1 pattern of the constants (codegen/joints.py)
-  SpecKernel algo[3];     // BRBD_ALGO_RNEA, BRBD_ALGO_ABA, BRBD_ALGO_FK_JAC
+  SpecKernel algo[4];     // BRBD_ALGO_RNEA, BRBD_ALGO_ABA, BRBD_ALGO_FK_JAC, BRBD_ALGO_RNEA_DERIV
 };
 
 // ---- memory access of the model-compiled kernels ------------------------------------------------
@@ -132,6 +132,8 @@ DI void spec_sincos(double x, double& so, double& co) {
 #define IN_X(k) (mx.get(k, ldx8))
 #define OUT(k, val) do { if (WANT & 1) mo.put(k, ldo8, val); } while (0)
 #define OUT2(k, val) do { if (WANT & 2) mo2.put(k, ldo28, val); } while (0)
+#define OUT3(k, val) do { if (WANT & 4) mo3.put(k, ldo38, val); } while (0)
+#define OUT4(k, val) do { if (WANT & 8) mo4.put(k, ldo48, val); } while (0)
 #define SINCOS(a, s, c) spec_sincos(a, s, c)
 #define RSQRT(a) rsqrt(a)
 #define RCP(a) (1.0 / (a))
@@ -179,6 +181,7 @@ DI void spec_sincos(double x, double& so, double& co) {
   const unsigned wsoff = blockIdx.x * (unsigned)(A.ws_stride * 8) + (unsigned)lane * 16u;            \
   const unsigned ldq8 = (unsigned)A.ldq * 8u, ldv8 = (unsigned)A.ldv * 8u, ldx8 = (unsigned)A.lda * 8u; \
   const unsigned ldo8 = (unsigned)A.ldout * 8u, ldo28 = (unsigned)A.ldout2 * 8u;                     \
+  const unsigned ldo38 = (unsigned)A.ldout3 * 8u, ldo48 = (unsigned)A.ldout4 * 8u;                   \
   int trace_ix = 0;                                                                                  \
   (void)lds2; (void)wsr; (void)wsoff; (void)trace_ix;
 
@@ -190,6 +193,8 @@ DI void spec_sincos(double x, double& so, double& co) {
   const SpecMat<LAYOUT> mx(A.a, A.nb[2], ldx8, inst);                                                \
   const SpecMat<LAYOUT> mo(A.out, A.nb[3], ldo8, inst);                                              \
   const SpecMat<LAYOUT> mo2(A.out2, A.nb[4], ldo28, inst);                                           \
-  (void)mv; (void)mx; (void)mo; (void)mo2;
+  const SpecMat<LAYOUT> mo3(A.out3, A.nb[5], ldo38, inst);                                           \
+  const SpecMat<LAYOUT> mo4(A.out4, A.nb[6], ldo48, inst);                                           \
+  (void)mv; (void)mx; (void)mo; (void)mo2; (void)mo3; (void)mo4; (void)ldo38; (void)ldo48;
 
 }  // namespace brbd

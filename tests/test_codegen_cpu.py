@@ -35,10 +35,44 @@ def test_generated_bodies_match_oracle(model, dense):
     assert rel_err_cols(tau, tau_ref).max() < 1e-12
     ddq = C.CpuKernel(mv, "aba", reg_budget=8, lds_budget=20).run(q, v, tau_ref, (model.nv, 0, 0))[0]
     assert rel_err_cols(ddq, O.aba(q, v, tau_ref)).max() < 1e-10
-    J, oMi, _ = C.CpuKernel(mv, "fkjac", reg_budget=0, lds_budget=12).run(
-        q, None, None, (6 * model.nv, 12 * model.njoints, 0))
+    J, oMi = C.CpuKernel(mv, "fkjac", reg_budget=0, lds_budget=12).run(
+        q, None, None, (6 * model.nv, 12 * model.njoints, 0))[:2]
     Jr, Mr = O.fk_jacobians(q)
     assert np.abs(J - Jr).max() < 1e-12 and np.abs(oMi - Mr).max() < 1e-12
+
+
+@pytest.mark.parametrize("model,dense", _models()[1:3] + _models()[4:6], ids=lambda x: getattr(x, "name", str(x)))
+def test_generated_derivative_bodies_match_oracle(model, dense):
+    """codegen/deriv.py (computeRNEADerivatives): all four outputs, every element of the three
+    nv x nv matrices written (structural zeros included: the outputs start as NaN here)."""
+    mv = joints.ModelView(model, dense=dense)
+    q, v, a = inputs(model, 6, 4)
+    nn = model.nv * model.nv
+    k = C.CpuKernel(mv, "deriv", reg_budget=8, lds_budget=24)
+    assert k.kernel.text.count("OUT(") == nn and k.kernel.text.count("OUT2(") == nn
+    assert k.kernel.text.count("OUT3(") == nn and k.kernel.text.count("OUT4(") == model.nv
+    dq, dv, da, tau = k.run(q, v, a, (nn, nn, nn, model.nv))
+    rq, rv, ra, rt = oracle.Oracle(model).rnea_derivatives(q, v, a)
+    for x, r in ((dq, rq), (dv, rv), (da, ra), (tau, rt)):
+        assert np.abs(x - r).max() / max(1.0, np.abs(r).max()) < 1e-12
+
+
+def test_fine_prefetch_placement_keeps_order():
+    """Emitter.text(fine=True): every early load of a parked value comes after the park's stores
+    and before its first use; the statements themselves keep their order."""
+    mv = joints.ModelView(S.arm7())
+    k0 = C.build_kernel(mv, "deriv")
+    lines = k0.text.splitlines()
+    stored, loaded = {}, {}
+    for n, ln in enumerate(lines):
+        for mac, d in (("PK_GLB_ST2(", stored), ("PK_LDS_ST2(", stored)):
+            if mac in ln:
+                d.setdefault((mac[3:6], int(ln.split(mac)[1].split(",")[0])), []).append(n)
+        for mac in ("PK_GLB_LD2(", "PK_LDS_LD2("):
+            if mac in ln:
+                slot = (mac[3:6], int(ln.split(mac)[1].split(",")[0]))
+                assert slot in stored and max(x for x in stored[slot] if x < n) < n
+    assert len(stored) > 0
 
 
 def test_pattern_folding_shrinks_the_humanoid():

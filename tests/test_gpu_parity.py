@@ -329,8 +329,15 @@ def _check_all(pool, model, O, B=130, seed=17):
     tau_ref = O.rnea(q, v, a)
     ddq_ref = O.aba(q, v, tau_ref)
     Jr, Mr = O.fk_jacobians(q)
+    der = O.rnea_derivatives(q, v, a) if model.is_depth_first() else None
     for order in "FC":
         qq, vv, aa, tt = (np.asarray(x, order=order) for x in (q, v, a, tau_ref))
+        if der is not None:
+            dq, dv, da, tau2 = parallel.computeRNEADerivatives(pool, qq, vv, aa, want_tau=True)
+            assert _mat_rel(dq, der[0]) < TOL_DERIV and _mat_rel(dv, der[1]) < TOL_DERIV
+            assert _mat_rel(da, der[2]) < TOL_DERIV and rel_err_cols(tau2, tau_ref).max() < TOL_RNEA
+            dq, dv, da = parallel.computeRNEADerivatives(pool, qq, vv, aa)  # (no tau: stores dropped)
+            assert _mat_rel(dq, der[0]) < TOL_DERIV and _mat_rel(dv, der[1]) < TOL_DERIV
         assert rel_err_cols(parallel.rneaInParallel(1, pool, qq, vv, aa), tau_ref).max() < TOL_RNEA
         assert rel_err_cols(parallel.abaInParallel(1, pool, qq, vv, tt), ddq_ref).max() < TOL_ABA
         J, oMi = parallel.computeJointJacobians(pool, qq, want_oMi=True)

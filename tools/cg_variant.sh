@@ -9,7 +9,7 @@ D=/tmp/cgv_$TAG; rm -rf $D; mkdir -p $D/gen
 env "$@" python -m pinocchio_amd.codegen.build --out $D/gen --models $MODEL --variants p 2>/dev/null
 FLAGS="$EXTRA -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-unused-variable -Wno-unused-but-set-variable -I pinocchio_amd/csrc"
 sed -i 's#"../brbd_spec.hpp"#"brbd_spec.hpp"#' $D/gen/spec_${MODEL}_p.hip
-( /opt/rocm/bin/hipcc $FLAGS -c -o $D/spec.o $D/gen/spec_${MODEL}_p.hip -Rpass-analysis=kernel-resource-usage 2>&1 | grep -E "Function Name|VGPRs:|AGPRs|Scratch|SGPRs Spill|VGPRs Spill" | grep -A5 "k_rneaIL\|k_abaIL" | sed 's/.*remark: *//;s/\[-Rpass.*//' | tr "\n" " " | sed "s/Function Name: _ZN4brbd22spec_${MODEL}_p/\n/g"; echo ) &
+( /opt/rocm/bin/hipcc $FLAGS -c -o $D/spec.o $D/gen/spec_${MODEL}_p.hip -Rpass-analysis=kernel-resource-usage 2>&1 | grep -E "Function Name|VGPRs:|AGPRs|Scratch|SGPRs Spill|VGPRs Spill" | grep -A5 "k_rneaIL\|k_abaIL\|k_derivIL" | sed 's/.*remark: *//;s/\[-Rpass.*//' | tr "\n" " " | sed "s/Function Name: _ZN4brbd22spec_${MODEL}_p/\n/g"; echo ) &
 sed -e 's#"gen/registry.inc"#"'$D'/gen/registry.inc"#' -e 's#"../../include/brbd.h"#"brbd.h"#' pinocchio_amd/csrc/brbd_capi.hip > $D/capi.hip
 /opt/rocm/bin/hipcc $FLAGS -I include -c -o $D/capi.o $D/capi.hip 2>&1 | grep -E "error"  &
 wait

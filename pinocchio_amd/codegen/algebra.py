@@ -137,6 +137,55 @@ def inertia_to_world(e: Emitter, R: Mat3, t: Sequence[V], c: Sequence[V], I: Seq
     return cw, Iw
 
 
+# ---- rigid-body inertia about the world origin: (m, h = m c, I_o); additive over bodies --------------
+def inertia_origin(e: Emitter, m: V, c: Sequence[V], I: Sequence[V]):
+    """(m, c, I_c) -> h = m c and I_o = I_c - m [c]x [c]x, the blocks of Inertia::matrix()
+    (spatial/inertia.hpp:480-491): [[m 1, -[h]x], [[h]x, I_o]]."""
+    h = vscale(e, m, c)
+    Io = [
+        e.add(I[0], e.fma(h[1], c[1], e.mul(h[2], c[2]))), e.fma(-h[0], c[1], I[1]),
+        e.add(I[2], e.fma(h[0], c[0], e.mul(h[2], c[2]))), e.fma(-h[0], c[2], I[3]),
+        e.fma(-h[1], c[2], I[4]), e.add(I[5], e.fma(h[0], c[0], e.mul(h[1], c[1]))),
+    ]
+    return h, Io
+
+
+def rbi_mul(e: Emitter, m: V, h: Sequence[V], Io: Sequence[V], x: Sequence[V]) -> Vec:
+    """[[m 1, -[h]x], [[h]x, I_o]] (a, b) = (m a + b x h, h x a + I_o b)"""
+    a, b = x[0:3], x[3:6]
+    return cross_add(e, b, h, vscale(e, m, a)) + sym3_mul(e, Io, b, cross(e, h, a))
+
+
+def rbi_variation(e: Emitter, m: V, h: Sequence[V], Io: Sequence[V], v: Sequence[V]):
+    """Inertia::variation(v) = crf(v) Y - Y crm(v) (spatial/inertia.hpp:584-603) keeps the block
+    structure [[0, -[dh]x], [[dh]x, dI]]: dh = m v.lin + w x h,
+    dI = [w]x I_o - I_o [w]x - ([v.lin]x [h]x + [h]x [v.lin]x), symmetric."""
+    vl, w = v[0:3], v[3:6]
+    dh = cross_add(e, w, h, vscale(e, m, vl))
+    rows = [[Io[0], Io[1], Io[3]], [Io[1], Io[2], Io[4]], [Io[3], Io[4], Io[5]]]
+    W = [cross(e, w, rows[c]) for c in range(3)]   # W[c][r] = ([w]x I_o)[r][c]
+    vh = e.dot(vl, h)
+    vh2 = e.add(vh, vh)
+
+    def entry(r, c):
+        x = e.add(W[c][r], W[r][c])
+        x = e.fma(-h[r], vl[c], e.fma(-vl[r], h[c], x))
+        return e.add(x, vh2) if r == c else x
+
+    dI = [entry(0, 0), entry(0, 1), entry(1, 1), entry(0, 2), entry(1, 2), entry(2, 2)]
+    return dh, dI
+
+
+def rbi_dot_mul(e: Emitter, hp: Sequence[V], hm: Sequence[V], dI: Sequence[V], n: Sequence[V],
+                x: Sequence[V], transpose: bool = False) -> Vec:
+    """(dY + forceCrossMatrix(oh)) x with dY = [[0, -[dh]x], [[dh]x, dI]], oh = (f, n), hp = dh + f,
+    hm = dh - f:  (b x hp, hm x a + dI b + b x n); transposed: (b x hm, hp x a + dI b + n x b)."""
+    a, b = x[0:3], x[3:6]
+    if transpose:
+        return cross(e, b, hm) + cross_add(e, hp, a, sym3_mul(e, dI, b, cross(e, n, b)))
+    return cross(e, b, hp) + cross_add(e, hm, a, sym3_mul(e, dI, b, cross(e, b, n)))
+
+
 # ---- packed symmetric 6x6 (21 entries, upper triangle, row-major) -----------------------------------
 def sidx(i: int, j: int) -> int:
     if i > j:

@@ -12,6 +12,7 @@ from __future__ import annotations
 import ctypes
 import hashlib
 import os
+import re
 import subprocess
 import tempfile
 from typing import Dict, Optional
@@ -27,7 +28,7 @@ ALGOS = {"rnea": rnea.generate, "aba": aba.generate, "fkjac": fkjac.generate, "d
 # storage budgets (doubles per lane) of the park planner, per algorithm:
 # (registers for short-lived parks, LDS, registers for long-lived parks)
 # LDS: 160 KiB per CU, 4 resident waves of 64 lanes at one wave per SIMD -> 80 doubles per lane
-BUDGETS = {"rnea": (40, 80, 0), "aba": (16, 80, 100, 64), "fkjac": (36, 80, 0), "deriv": (40, 80, 0, 64)}
+BUDGETS = {"rnea": (40, 80, 0), "aba": (16, 80, 100, 64), "fkjac": (36, 80, 0), "deriv": (64, 80, 32, 64)}  # (deriv: first rung of LADDER)
 for _a in list(BUDGETS):  # experiment hook: BRBD_CG_ABA="64,80"
     _v = os.environ.get("BRBD_CG_" + _a.upper())
     if _v:
@@ -47,6 +48,44 @@ for _a in list(ALGOS):  # experiment hook: BRBD_CG_AHEAD_DERIV="glb=200,in=100"
 FINE = set(os.environ.get("BRBD_CG_FINE", "deriv").split(","))
 
 
+# Budget ladder: the budgets above suit the models they were tuned on; a larger model has enough
+# parks to fill every class to its limit at once.  ``build_kernel`` walks down the ladder until
+# the body's register-pressure estimate (doubles live in program order) fits: hipcc spills to
+# scratch beyond ~200 doubles (512 registers per lane at one wave per SIMD, minus addressing).
+LADDER = {"deriv": [(64, 80, 32, 64), (40, 80, 32, 64), (24, 80, 16, 64), (8, 80, 0, 64), (0, 80, 0, 64),
+                    (0, 80, 0, 48), (0, 80, 0, 24)]}
+LIVE_MAX = {"deriv": 190}
+
+_IDENT = re.compile(r"\b([a-z][a-z]?_?[0-9]+(?:_[0-9]+)?|[sc]_t[0-9]+)\b")
+
+
+def liveness_peak(text: str) -> int:
+    """Most doubles live after any statement of a generated body, in program order (constants of
+    the scalar table excluded).  tools/cg_liveness.py prints the same per visit."""
+    stm, uses = [], {}
+    for ln, line in enumerate(text.splitlines()):
+        if line.startswith("/*") or line.startswith("VISIT_END"):
+            stm.append(((), ()))
+            continue
+        ids = _IDENT.findall(line)
+        m = re.match(r"(?:const )?double ([^=;]+?)(?: =|;)", line)
+        d = [x.strip() for x in m.group(1).split(",")] if m else []
+        u = [x for x in ids if x not in d]
+        stm.append((d, u))
+        for x in u:
+            uses[x] = ln
+    live, peak = set(), 0
+    for ln, (d, u) in enumerate(stm):
+        for x in d:
+            if x in uses and not x.startswith("k"):
+                live.add(x)
+        for x in u:
+            if uses.get(x) == ln:
+                live.discard(x)
+        peak = max(peak, len(live))
+    return peak
+
+
 class Kernel:
     def __init__(self, algo, text, const_list, lds, glb, stats, nvisits):
         self.algo, self.text, self.const_list = algo, text, const_list
@@ -56,14 +95,22 @@ class Kernel:
 def build_kernel(mv: joints.ModelView, algo: str, reg_budget: Optional[int] = None,
                  lds_budget: Optional[int] = None) -> Kernel:
     gen = ALGOS[algo]
-    rb, lb, rl = BUDGETS[algo][:3]
-    rt = BUDGETS[algo][3] if len(BUDGETS[algo]) > 3 else 64
-    rb = rb if reg_budget is None else reg_budget
-    lb = lb if lds_budget is None else lds_budget
+    ahead = dict(AHEAD, **AHEAD_ALGO.get(algo, {}))
     dry = gen(mv, Emitter())
-    plan, lds, glb = plan_storage(dry.parks, rb, lb, rl, rt)
-    e = gen(mv, Emitter(plan))
-    return Kernel(algo, e.text(dict(AHEAD, **AHEAD_ALGO.get(algo, {})), algo in FINE), list(e.const_list), lds, glb, dict(e.stats), len(e.visits))
+    ladder = [BUDGETS[algo]]
+    if reg_budget is None and lds_budget is None and ("BRBD_CG_" + algo.upper()) not in os.environ:
+        ladder = LADDER.get(algo, ladder)
+    for budget in ladder:
+        rb, lb, rl = budget[:3]
+        rt = budget[3] if len(budget) > 3 else 64
+        rb = rb if reg_budget is None else reg_budget
+        lb = lb if lds_budget is None else lds_budget
+        plan, lds, glb = plan_storage(dry.parks, rb, lb, rl, rt)
+        e = gen(mv, Emitter(plan))
+        text = e.text(ahead, algo in FINE)
+        if len(ladder) == 1 or liveness_peak(text) <= LIVE_MAX[algo]:
+            break
+    return Kernel(algo, text, list(e.const_list), lds, glb, dict(e.stats), len(e.visits))
 
 
 def pack_constants(mv: joints.ModelView, const_list) -> np.ndarray:

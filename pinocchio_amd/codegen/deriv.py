@@ -5,27 +5,32 @@ nv x nv column-major per instance (element (row, col) at col * nv + row), every 
 World-frame recursion like the reference.  Forward visit of joint i (:263-338): oMi, J = oMi.act(S),
 ov, oa_gf (world form of :285-305: oa_gf_i = oa_gf_p + J a + ov_i x (J v)), and per dof the columns
 dVdq = ov_p x J, dAdq = oa_gf_p x J + ov_p x dVdq, dAdv = ov_i x J + dVdq (:319-331).  Backward visit
-(:378-459): composite oYcrb (packed symmetric 6x6, additive in the world frame), doYcrb =
-oYcrb.variation(ov) + forceCrossMatrix(oh) (:335-337, written as -(P + P^T) with P = Y crm(ov)),
-of; then tau = J^T of, dFda = Y J, dFdq = doY dVdq + Y dAdq (+ J x* of), dFdv = doY J + Y dAdv,
+(:378-459): composite oYcrb as the 10 numbers of a rigid-body inertia about the world origin (m,
+h = m c, I_o: additive over the subtree), doYcrb = oYcrb.variation(ov) + forceCrossMatrix(oh)
+(:335-337) as the 9 numbers of the variation (dh, dI: it keeps the block structure) plus the
+composite oh, of; then tau = J^T of, dFda = Y J, dFdq = doY dVdq + Y dAdq (+ J x* of), dFdv = doY J + Y dAdv,
 dYtJ = J^T doY.
 
 The reference fills, at an ANCESTOR's backward visit, the blocks that couple it with every dof of
 its subtree, which keeps 24 doubles per dof of the whole subtree alive until the root.  Here the
-same dot products are evaluated at the DESCENDANT's backward visit, streaming over the joints on
-its root path (one short visit per ancestor): what stays alive is the path, not the subtree.
+same dot products are evaluated from the DESCENDANT's side, streaming over the joints on its root
+path: what stays alive is the path, not the subtree.  The pair visits of a chain of joints whose
+backward visits follow each other (a limb on the way up) are deferred and done together, ancestor
+by ancestor (at most CHAIN dofs at a time): the ancestor's columns are loaded once per group, and
+the composite quantities pass from child to parent in registers.  The columns of a joint attached
+to the universe are recomputed from its placement and velocity (18 doubles) instead of parked
+(24 per dof): with the output matrices, the parked state is what the kernel's HBM time is made of.
 """
 from __future__ import annotations
+
+import os
 
 from . import algebra as A
 from . import joints as J
 from .emit import ZERO, Emitter, V
 
 
-def crm_col(e: Emitter, v, j: int):
-    """column j of the motion cross matrix of v: v x e_j"""
-    unit = [V(num=1.0) if k == j else ZERO for k in range(6)]
-    return A.motion_cross(e, v, unit)
+CHAIN = int(os.environ.get("BRBD_CG_CHAIN", "3"))  # dofs per deferred group of pair visits
 
 
 def generate(mv: J.ModelView, e: Emitter) -> Emitter:
@@ -36,12 +41,60 @@ def generate(mv: J.ModelView, e: Emitter) -> Emitter:
         e.out(col * nvt + row, val, which)
         written[which].add((row, col))
 
-    kin = {}      # joint -> Park R(9) t(3) ov(6) oa_gf(6)
-    vec = {}      # joint -> Park per dof: J, dVdq, dAdq, dAdv (24 per dof)
-    acc = {}      # joint -> Park of the finished children's oYcrb (21) + doYcrb (36) + of (6)
+    kin = {}      # joint -> Park R(9) t(3) ov(6) [oa_gf(6) in kin_oa for joints attached to the universe]
+    kin_oa = {}
+    vec = {}      # joint -> Park per dof: J, dVdq, dAdq, dAdv (24 per dof); none for universe children
+    deferred = [] # (joint, Park of its own dFda / dYtJ / dFdq / dFdv columns), deepest first
 
-    def mat6_mul(Mx, x):
-        return [e.dot(Mx[r], x) for r in range(6)]
+    def root_col(i, R, t, ov, k):
+        """columns of dof k of a joint attached to the universe (:331: dVdq = 0, oa_gf[0] = -gravity)"""
+        g = mv.gravity(e)
+        oap = [-g[0], -g[1], -g[2], ZERO, ZERO, ZERO]
+        Jk = A.act_motion(e, R, t, J.subspace(e, mv, i)[k])
+        return (Jk, A.zeros(6), A.motion_cross(e, oap, Jk), A.motion_cross(e, ov, Jk))
+
+    def pair(iv_k, o, iva_r, ca):
+        fa, yt, fq, fv = (o[6 * j:6 * j + 6] for j in range(4))
+        Ja, dVa, dAqa, dAva = ca
+        put(3, iva_r, iv_k, A.dot6(e, Ja, fa))                                   # :420-421
+        put(1, iv_k, iva_r, A.dot6(e, yt, dVa, A.dot6(e, fa, dAqa)))             # :433-435
+        put(1, iva_r, iv_k, A.dot6(e, Ja, fq))                                   # :437-438
+        put(2, iv_k, iva_r, A.dot6(e, yt, Ja, A.dot6(e, fa, dAva)))              # :446-448
+        put(2, iva_r, iv_k, A.dot6(e, Ja, fv))                                   # :450-451
+
+    def flush():
+        """the blocks that couple the deferred joints with every joint on their root path"""
+        group = list(deferred)
+        del deferred[:]
+        if not group:
+            return
+        members = [d for d, _ in group]
+        names = "+".join(str(d) for d in members)
+        a = mv.parents[members[0]]
+        while a > 0:
+            below = group[:members.index(a)] if a in members else group
+            nva, iva = mv.nv(a), mv.idx_v[a]
+            if mv.parents[a] == 0:
+                e.begin_visit("PAIR %s x %d" % (names, a))
+                st = e.unpark(kin[a])
+                owns = [(d, e.unpark(own)) for d, own in below]
+                for r in range(nva):
+                    ca = root_col(a, [st[0:3], st[3:6], st[6:9]], st[9:12], st[12:18], r)
+                    for d, o in owns:
+                        for k in range(mv.nv(d)):
+                            pair(mv.idx_v[d] + k, o[24 * k:24 * k + 24], iva + r, ca)
+            else:
+                for r in range(nva):
+                    e.begin_visit("PAIR %s x %d%s" % (names, a, "" if nva == 1 else ", dof %d" % r))
+                    va = e.unpark(vec[a][r])
+                    ca = tuple(va[6 * j:6 * j + 6] for j in range(4))
+                    for d, own in below:
+                        o = e.unpark(own)
+                        for k in range(mv.nv(d)):
+                            pair(mv.idx_v[d] + k, o[24 * k:24 * k + 24], iva + r, ca)
+            a = mv.parents[a]
+    acc = {}      # joint -> Park of the finished children's composite m, h, I_o (oYcrb), dh, dI (doYcrb
+                  # without its force-cross part), oh, of: 31 doubles
 
     def backward(i, R, t, ov, oa_gf, Jc, cols):
         """Jc: the joint's world-frame columns; cols(k) -> (J, dVdq, dAdq, dAdv) of dof k"""
@@ -49,32 +102,24 @@ def generate(mv: J.ModelView, e: Emitter) -> Emitter:
         nv, iv = mv.nv(i), mv.idx_v[i]
         m, c, I = mv.inertia(e, i)
         cw, Iw = A.inertia_to_world(e, R, t, c, I)            # :302
-        Y = A.inertia_to_sym6(e, m, cw, Iw)
-        oh = A.sym6_mulvec(e, Y, ov)                           # :307
-        of = A.vadd(e, A.sym6_mulvec(e, Y, oa_gf), A.force_cross(e, ov, oh))  # :308
-        # :335 oYcrb.variation(ov) = crf(ov) Y - Y crm(ov) = -(P^T + P), P = Y crm(ov)
-        P = [A.sym6_mulvec(e, Y, crm_col(e, ov, j)) for j in range(6)]   # P[j] = column j
-        dY = [[-e.add(P[cc][r], P[r][cc]) for cc in range(6)] for r in range(6)]
-        # :337 addForceCrossMatrix(oh): skew(-f.lin) on the LA and AL blocks, skew(-f.ang) on AA
-        def skew(v3):
-            return [[ZERO, -v3[2], v3[1]], [v3[2], ZERO, -v3[0]], [-v3[1], v3[0], ZERO]]
-        sl, sa = skew([-x for x in oh[0:3]]), skew([-x for x in oh[3:6]])
-        for r in range(3):
-            for cc in range(3):
-                dY[r][3 + cc] = e.add(dY[r][3 + cc], sl[r][cc])
-                dY[3 + r][cc] = e.add(dY[3 + r][cc], sl[r][cc])
-                dY[3 + r][3 + cc] = e.add(dY[3 + r][3 + cc], sa[r][cc])
+        h, Io = A.inertia_origin(e, m, cw, Iw)
+        oh = A.rbi_mul(e, m, h, Io, ov)                        # :307
+        of = A.vadd(e, A.rbi_mul(e, m, h, Io, oa_gf), A.force_cross(e, ov, oh))  # :308
+        dh, dI = A.rbi_variation(e, m, h, Io, ov)              # :335 (of the body's own inertia)
         if i in acc:  # children's composite quantities (:453-458)
             vals = e.unpark(acc.pop(i))
-            Y = A.vadd(e, Y, vals[0:21])
-            dY = [[e.add(dY[r][cc], vals[21 + 6 * r + cc]) for cc in range(6)] for r in range(6)]
-            of = A.vadd(e, of, vals[57:63])
-        # hand the composite quantities to the parent (:453-458)
-        if p > 0:
-            up = list(Y) + [dY[r][cc] for r in range(6) for cc in range(6)] + list(of)
-            if p in acc:
-                up = A.vadd(e, e.unpark(acc[p]), up)
-            acc[p] = e.park(up, "stack")
+            m, h, Io = e.add(m, vals[0]), A.vadd(e, h, vals[1:4]), A.vadd(e, Io, vals[4:10])
+            dh, dI = A.vadd(e, dh, vals[10:13]), A.vadd(e, dI, vals[13:19])
+            oh, of = A.vadd(e, oh, vals[19:25]), A.vadd(e, of, vals[25:31])
+        # :337 doYcrb += forceCrossMatrix(oh): not symmetric, carried as oh itself
+        hp, hm, hn = A.vadd(e, dh, oh[0:3]), A.vsub(e, dh, oh[0:3]), oh[3:6]
+
+        def Ymul(x):
+            return A.rbi_mul(e, m, h, Io, x)
+
+        def dYmul(x, transpose=False):
+            return A.rbi_dot_mul(e, hp, hm, dI, hn, x, transpose)
+
         # own columns, one dof at a time (a free-flyer's six columns of dFda / dFdq / dFdv at once
         # would not fit the register file); the values above stay in registers across the sub-visits
         own_vals = []
@@ -82,11 +127,11 @@ def generate(mv: J.ModelView, e: Emitter) -> Emitter:
             if k > 0:
                 e.begin_visit("BWD %d, dof %d" % (i, k))
             Jk, dVk, dAqk, dAvk = cols(k)
-            dFda = A.sym6_mulvec(e, Y, Jk)                                             # :419
+            dFda = Ymul(Jk)                                                            # :419
             if p > 0:                                                                  # :424-430
-                dFdq = A.vadd(e, mat6_mul(dY, dVk), A.sym6_mulvec(e, Y, dAqk))
+                dFdq = A.vadd(e, dYmul(dVk), Ymul(dAqk))
             else:
-                dFdq = A.sym6_mulvec(e, Y, dAqk)
+                dFdq = Ymul(dAqk)
             tau = A.dot6(e, Jk, of)                                                    # :409-410
             arm = mv.c(e, i, "arm", iv + k)
             if not arm.is_zero():
@@ -99,35 +144,25 @@ def generate(mv: J.ModelView, e: Emitter) -> Emitter:
                 put(3, iv + r, iv + k, mrk)
                 put(1, iv + r, iv + k, A.dot6(e, Jc[r], dFdq))                         # :437-438
             dFdq = A.vadd(e, dFdq, A.force_cross(e, Jk, of))                           # :440
-            dFdv = A.vadd(e, mat6_mul(dY, Jk), A.sym6_mulvec(e, Y, dAvk))              # :443-444
+            dFdv = A.vadd(e, dYmul(Jk), Ymul(dAvk))                                    # :443-444
             for r in range(nv):
                 put(2, iv + r, iv + k, A.dot6(e, Jc[r], dFdv))                         # :450-451
             if p > 0:
-                dYtJ = [e.dot(Jk, [dY[r][cc] for r in range(6)]) for cc in range(6)]   # :432
+                dYtJ = dYmul(Jk, transpose=True)                                       # :432
                 own_vals += dFda + dYtJ + dFdq + dFdv
-        # the blocks that couple this joint with every joint on its root path
-        a = p
-        own = None
-        while a > 0:
-            if own is None:
-                # keep the own columns across the ancestor visits
-                own = e.park(own_vals, "tail")
-            nva, iva = mv.nv(a), mv.idx_v[a]
-            for r in range(nva):  # (one visit per dof of the ancestor: a free-flyer's 6 x 24 values)
-                e.begin_visit("PAIR %d x %d%s" % (i, a, "" if nva == 1 else ", dof %d" % r))
-                o = e.unpark(own)
-                va = e.unpark(vec[a][r])
-                Ja, dVa, dAqa, dAva = (va[6 * j:6 * j + 6] for j in range(4))
-                for k in range(nv):
-                    fa, yt, fq, fv = (o[24 * k + 6 * j:24 * k + 6 * j + 6] for j in range(4))
-                    put(3, iva + r, iv + k, A.dot6(e, Ja, fa))                                   # :420-421
-                    put(1, iv + k, iva + r, A.dot6(e, yt, dVa, A.dot6(e, fa, dAqa)))             # :433-435
-                    put(1, iva + r, iv + k, A.dot6(e, Ja, fq))                                   # :437-438
-                    put(2, iv + k, iva + r, A.dot6(e, yt, Ja, A.dot6(e, fa, dAva)))              # :446-448
-                    put(2, iva + r, iv + k, A.dot6(e, Ja, fv))                                   # :450-451
-            a = mv.parents[a]
+        # hand the composite quantities to the parent (:453-458); in registers when the
+        # parent's backward visit is the next one
+        if p > 0:
+            up = [m] + list(h) + list(Io) + list(dh) + list(dI) + list(oh) + list(of)
+            if p in acc:
+                up = A.vadd(e, e.unpark(acc[p]), up)
+            # (the running sum of a joint attached to the universe lives across whole limbs: "hand")
+            acc[p] = e.park(up, "stack" if mv.parents[p] > 0 else "hand")
+        if p > 0:
+            deferred.append((i, e.park(own_vals, "tail")))
 
-    for kind, i in J.visit_program(mv):
+    program = list(J.visit_program(mv))
+    for step, (kind, i) in enumerate(program):
         p = mv.parents[i]
         leaf = not mv.children[i]
         nv, iv = mv.nv(i), mv.idx_v[i]
@@ -139,7 +174,8 @@ def generate(mv: J.ModelView, e: Emitter) -> Emitter:
                 ovp, oap = A.zeros(6), [-g[0], -g[1], -g[2], ZERO, ZERO, ZERO]
             else:
                 st = e.unpark(kin[p])
-                Rp, tp, ovp, oap = [st[0:3], st[3:6], st[6:9]], st[9:12], st[12:18], st[18:24]
+                Rp, tp, ovp = [st[0:3], st[3:6], st[6:9]], st[9:12], st[12:18]
+                oap = st[18:24] if mv.parents[p] > 0 else e.unpark(kin_oa[p])
             Rl, tl, _ = J.joint_transform(e, mv, i)
             if p == 0:
                 R, t = Rl, tl
@@ -168,28 +204,35 @@ def generate(mv: J.ModelView, e: Emitter) -> Emitter:
                 cols.append((Jc[k], dVdq, dAdq, dAdv))
             if leaf:
                 backward(i, R, t, ov, oa, Jc, lambda k: cols[k])
-            else:
+            elif p > 0:
                 vec[i] = [e.park([x for vv in cset for x in vv], "stack") for cset in cols]
                 kin[i] = e.park([x for row in R for x in row] + list(t) + ov + oa, "stack")
+            else:
+                kin[i] = e.park([x for row in R for x in row] + list(t) + ov, "stack")
+                kin_oa[i] = e.park(oa, "stack")
         elif not leaf:
+            if deferred and sum(mv.nv(d) for d, _ in deferred) + nv > CHAIN:
+                flush()
             e.begin_visit("BWD %d" % i)
             st = e.unpark(kin[i])
-            R, t, ov, oa = [st[0:3], st[3:6], st[6:9]], st[9:12], st[12:18], st[18:24]
+            R, t, ov = [st[0:3], st[3:6], st[6:9]], st[9:12], st[12:18]
             if p > 0:  # (ancestors of later joints read these parks too)
                 vv = [e.unpark(pk) for pk in vec[i]]
-                backward(i, R, t, ov, oa, [x[0:6] for x in vv],
+                backward(i, R, t, ov, st[18:24], [x[0:6] for x in vv],
                          lambda k: tuple(vv[k][6 * j:6 * j + 6] for j in range(4)))
-            else:      # root: each dof's dVdq / dAdq / dAdv only in its own sub-visit
-                def col(k):
-                    x = e.unpark(vec[i][k])
-                    return tuple(x[6 * j:6 * j + 6] for j in range(4))
-                Jroot = [e.unpark(pk)[0:6] for pk in vec[i]]
-                backward(i, R, t, ov, oa, Jroot, col)
-    # everything else is structurally zero (unrelated branches; lower triangle of dtau/da)
-    e.begin_visit("ZEROS")
+            else:
+                Jroot = [A.act_motion(e, R, t, col) for col in J.subspace(e, mv, i)]
+                backward(i, R, t, ov, e.unpark(kin_oa[i]), Jroot, lambda k: root_col(i, R, t, ov, k))
+        # pair visits of the joints whose backward visits have run, once the walk turns downwards
+        # again (or the group is full)
+        nxt = program[step + 1][0] if step + 1 < len(program) else "F"
+        if deferred and (nxt == "F" or sum(mv.nv(d) for d, _ in deferred) >= CHAIN):
+            flush()
+    # everything else is structurally zero (unrelated branches; lower triangle of dtau/da): spread
+    # over the whole body (Emitter.out_filler)
     for which in (1, 2, 3):
         for col in range(nvt):
             for row in range(nvt):
                 if (row, col) not in written[which]:
-                    e.out(col * nvt + row, ZERO, which)
+                    e.out_filler(col * nvt + row, ZERO, which)
     return e

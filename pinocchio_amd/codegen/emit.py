@@ -22,6 +22,7 @@ second pass emits the loads of a parked value one visit ahead of its use.
 from __future__ import annotations
 
 import math
+import re
 import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -85,6 +86,9 @@ for _kv in os.environ.get("BRBD_CG_AHEAD", "").split(","):
     if "=" in _kv:
         AHEAD[_kv.split("=")[0]] = int(_kv.split("=")[1])
 
+_NAME = re.compile(r"\b[a-z][a-z]?_?[0-9]+(?:_[0-9]+)?\b")
+_DECL = re.compile(r"(?:const )?double ([^=;]+?)(?: =|;)")
+
 ZERO = V(num=0.0)
 ONE = V(num=1.0)
 
@@ -123,6 +127,7 @@ class Emitter:
         self.const_cache: Dict[tuple, V] = {}
         self.in_cache: Dict[tuple, V] = {}
         self.stats = {"fp": 0, "ld": 0, "st": 0, "ct": 0, "trans": 0}
+        self.fillers: List[str] = []  # stores that depend on nothing (structural zeros)
         self.opaque_regs = False  # experiment: made register pressure worse with hipcc 7.2
 
     # ---- visits --------------------------------------------------------------------------
@@ -188,6 +193,16 @@ class Emitter:
     def out(self, k: int, x: V, which: int = 1):
         mac = "OUT" if which == 1 else "OUT%d" % which
         self.stmt("%s(%d, %s);" % (mac, k, x.code()))
+        self.stats["st"] += 1
+
+    def out_filler(self, k: int, x: V, which: int = 1):
+        """An output that depends on no computed value (a structural zero): text() spreads these
+        evenly over the whole body, so that they drain while the arithmetic runs.  All waves of a
+        launch run the same program in step: a burst of stores at one place is a phase in which
+        every wave waits for HBM and no wave computes."""
+        assert x.is_num
+        mac = "OUT" if which == 1 else "OUT%d" % which
+        self.fillers.append("%s(%d, %s);" % (mac, k, x.code()))
         self.stats["st"] += 1
 
     # ---- arithmetic with folding -------------------------------------------------------------
@@ -365,9 +380,9 @@ class Emitter:
         SIMD nothing else hides memory latency: HBM wants thousands of cycles of distance, LDS and
         the scalar cache a few hundred.  (Visits differ in length by 20x, so a distance counted in
         visits either starves the long ones or floods the registers in the short ones.)
-        ``fine``: place each early load exactly ahead[kind] statements before its visit, inside the
-        body of the earlier visit, instead of bunching them at visit starts (lower register peaks
-        when many short visits each consume a parked block)."""
+        ``fine``: place each early load exactly ahead[kind] statements before its first use, inside
+        the body of the earlier visit (or of its own), instead of bunching them at visit starts
+        (lower register peaks when many short visits each consume a parked block)."""
         ahead = ahead or AHEAD
         n = len(self.visits)
         size = [len(v.body) for v in self.visits]
@@ -377,8 +392,16 @@ class Emitter:
                 start[k + 1] = start[k] + size[k]
             ins: Dict[int, List[str]] = {}
             for k in range(n):
+                # first statement of the visit that reads each name
+                first: Dict[str, int] = {}
+                for j, st in enumerate(self.visits[k].body):
+                    for name in _NAME.findall(st):
+                        first.setdefault(name, j)
                 for line, kind, earliest in self.visits[k].pre:
-                    pos = max(start[min(max(earliest, 0), k)], start[k] - ahead.get(kind, 0))
+                    m = _DECL.match(line)
+                    names = [x.strip() for x in m.group(1).split(",")] if m else []
+                    use = min([first[x] for x in names if x in first] or [0])
+                    pos = max(start[min(max(earliest, 0), k)], start[k] + use - ahead.get(kind, 0))
                     ins.setdefault(pos, []).append(line)
             lines = []
             for k in range(n):
@@ -392,7 +415,7 @@ class Emitter:
                     pass
                 lines.append("VISIT_END();")
             assert not ins.get(start[n]), "early load after the last statement"
-            return "\n".join(lines) + "\n"
+            return "\n".join(self._spread(lines)) + "\n"
         early: List[List[str]] = [[] for _ in range(n)]
         for k in range(n):
             for line, kind, earliest in self.visits[k].pre:
@@ -408,7 +431,42 @@ class Emitter:
             lines.append("/* ---- visit %d: %s ---- */" % (k, self.visits[k].label))
             lines += self.visits[k].body
             lines.append("VISIT_END();")
-        return "\n".join(lines) + "\n"
+        return "\n".join(self._spread(lines)) + "\n"
+
+    def _spread(self, lines: List[str], window: int = 128) -> List[str]:
+        """Place the filler stores where the body has the least memory traffic of its own
+        (water-filling over windows of ``window`` statements; a b128 park access counts as two)."""
+        if not self.fillers:
+            return lines
+        at = [n for n, ln in enumerate(lines) if not ln.startswith("/*") and not ln.startswith("VISIT_END")]
+        nwin = max(1, len(at) // window)
+        load = [0.0] * nwin
+        for j, n in enumerate(at):
+            ln = lines[n]
+            w = min(j * nwin // len(at), nwin - 1)
+            if "PK_GLB_" in ln:
+                load[w] += 2
+            elif ln.startswith("OUT") or "IN_" in ln:
+                load[w] += 1
+        import heapq
+        heap = [(load[w], w) for w in range(nwin)]
+        heapq.heapify(heap)
+        count = [0] * nwin
+        for _ in self.fillers:
+            l, w = heapq.heappop(heap)
+            count[w] += 1
+            heapq.heappush(heap, (l + 1, w))
+        where: Dict[int, List[str]] = {}
+        it = iter(self.fillers)
+        for w in range(nwin):
+            lo, hi = w * len(at) // nwin, (w + 1) * len(at) // nwin
+            for j in range(count[w]):
+                where.setdefault(at[lo + (j * (hi - lo)) // count[w]], []).append(next(it))
+        out: List[str] = []
+        for n, ln in enumerate(lines):
+            out.append(ln)
+            out += where.get(n, [])
+        return out
 
 
 def plan_storage(parks: Sequence[Park], reg_short: int, lds_budget: int, reg_long: int = 0, reg_tail: int = 64):

@@ -292,7 +292,8 @@ int launch_algo(brbd_model* m, int algo, KArgs& A, int layout, hipStream_t strea
   // the wave-private global area, so that the area stays bounded (8 rounds of resident waves).
   int64_t grid = A.ntiles < resident ? A.ntiles : resident;
   if (stat) {
-    int64_t chunk = sk->glb_doubles > 0 ? resident * 8 : A.ntiles;
+    static const int rounds = getenv("BRBD_CHUNK_ROUNDS") ? atoi(getenv("BRBD_CHUNK_ROUNDS")) : 8;
+    int64_t chunk = sk->glb_doubles > 0 ? resident * (rounds > 0 ? rounds : 1) : A.ntiles;
     const int64_t cap = (int64_t)(4000000000.0 / ((double)per_lane * WAVE * 8));  // 32-bit park offsets
     if (chunk > cap) chunk = cap;
     grid = A.ntiles < chunk ? A.ntiles : chunk;

@@ -180,6 +180,16 @@ int brbd_transpose_to_instance_major(int device, int64_t dof, int64_t B, const d
 const char* brbd_model_compiled_kernels(const brbd_model* m);
 int brbd_model_use_compiled(brbd_model* m, int enabled);
 
+/* Output contract of brbd_rnea_derivatives.  The reference requires the caller to zero the three
+ * matrices before the call and fills only the entries that couple a joint with its own subtree
+ * and root path (include/pinocchio/algorithm/rnea-derivatives.hpp:104-106: "must be first
+ * initialized with zeros").  Default here (0): every element is written, structural zeros
+ * included, so the outputs need no clearing.  1 = the reference's contract: the caller has zeroed
+ * dtau_dq / dtau_dv / dtau_da and the structural zeros are not written again, which saves their
+ * HBM traffic (41% of the stores for a quadruped).  Honoured by the model-compiled kernels; the
+ * table-driven kernel writes every element in both modes (same result). */
+int brbd_model_outputs_prezeroed(brbd_model* m, int enabled);
+
 /* Kernel timing for the roofline (bench.py): with timing enabled every kernel launch of the
  * engine is bracketed by hipEvents recorded on the launch stream.  brbd_kernel_time() waits for
  * the recorded launches of `algo` (enum brbd_algo), returns how many there were and their summed

@@ -34,7 +34,7 @@ SYMBOLS = (
     "brbd_model_create", "brbd_model_destroy", "brbd_model_dims", "brbd_workspace_bytes",
     "brbd_rnea", "brbd_aba", "brbd_fk_jacobians", "brbd_rnea_derivatives",
     "brbd_transpose_to_batch_major", "brbd_transpose_to_instance_major",
-    "brbd_set_timing", "brbd_kernel_time", "brbd_model_compiled_kernels", "brbd_model_use_compiled",
+    "brbd_set_timing", "brbd_kernel_time", "brbd_model_compiled_kernels", "brbd_model_use_compiled", "brbd_model_outputs_prezeroed",
 )
 
 
@@ -113,6 +113,8 @@ def lib():
     L.brbd_model_compiled_kernels.argtypes = [vp]
     L.brbd_model_use_compiled.restype = ci
     L.brbd_model_use_compiled.argtypes = [vp, ci]
+    L.brbd_model_outputs_prezeroed.restype = ci
+    L.brbd_model_outputs_prezeroed.argtypes = [vp, ci]
     L.brbd_set_timing.restype = ci
     L.brbd_set_timing.argtypes = [vp, ci]
     L.brbd_kernel_time.restype = ci
@@ -170,6 +172,10 @@ class DeviceModel:
 
     def use_compiled(self, on: bool):
         check(lib().brbd_model_use_compiled(self.handle, 1 if on else 0))
+
+    def outputs_prezeroed(self, on: bool):
+        """Derivative outputs under the reference's contract (caller zeroed them): see include/brbd.h"""
+        check(lib().brbd_model_outputs_prezeroed(self.handle, 1 if on else 0))
 
     def set_timing(self, on: bool):
         check(lib().brbd_set_timing(self.handle, 1 if on else 0))

@@ -128,6 +128,15 @@ _CPU_SHELL = r"""
 #define OUT2(k, val) out2[k] = (val)
 #define OUT3(k, val) out3[k] = (val)
 #define OUT4(k, val) out4[k] = (val)
+#ifdef SKIP_ZEROS
+#define OUTZ(k) do { } while (0)
+#define OUT2Z(k) do { } while (0)
+#define OUT3Z(k) do { } while (0)
+#else
+#define OUTZ(k) out[k] = 0.0
+#define OUT2Z(k) out2[k] = 0.0
+#define OUT3Z(k) out3[k] = 0.0
+#endif
 #define SINCOS(a, s, c) sincos(a, &s, &c)
 #define RSQRT(a) (1.0 / sqrt(a))
 #define RCP(a) (1.0 / (a))
@@ -157,7 +166,7 @@ void spec_batch(const double* ct, long B, const double* q, long ldq, const doubl
 class CpuKernel:
     """The generated body compiled for the host (checker of the generator, never a product path)."""
 
-    def __init__(self, mv: joints.ModelView, algo: str, **kw):
+    def __init__(self, mv: joints.ModelView, algo: str, skip_zeros: bool = False, **kw):
         self.mv, self.kernel = mv, build_kernel(mv, algo, **kw)
         self.ct = pack_constants(mv, self.kernel.const_list)
         self.dir = tempfile.mkdtemp(prefix="brbd_cg_")
@@ -170,7 +179,8 @@ class CpuKernel:
                 "GLB_N", str(self.kernel.glb)))
         so = os.path.join(self.dir, "spec.so")
         # -ffp-contract=off: only the FMAs the generator asked for
-        subprocess.check_call(["gcc", "-O1", "-ffp-contract=off", "-shared", "-fPIC", "-o", so, src, "-lm"])
+        subprocess.check_call(["gcc", "-O1", "-ffp-contract=off", "-shared", "-fPIC", "-o", so, src, "-lm"]
+                              + (["-DSKIP_ZEROS"] if skip_zeros else []))
         self.lib = ctypes.CDLL(so)
         dp, l = ctypes.POINTER(ctypes.c_double), ctypes.c_long
         self.lib.spec_batch.argtypes = [dp, l, dp, l, dp, l, dp, l, dp, l, dp, l, dp, l, dp, l]

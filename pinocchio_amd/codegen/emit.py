@@ -200,9 +200,9 @@ class Emitter:
         evenly over the whole body, so that they drain while the arithmetic runs.  All waves of a
         launch run the same program in step: a burst of stores at one place is a phase in which
         every wave waits for HBM and no wave computes."""
-        assert x.is_num
-        mac = "OUT" if which == 1 else "OUT%d" % which
-        self.fillers.append("%s(%d, %s);" % (mac, k, x.code()))
+        assert x.is_zero()
+        mac = "OUTZ" if which == 1 else "OUT%dZ" % which
+        self.fillers.append("%s(%d);" % (mac, k))
         self.stats["st"] += 1
 
     # ---- arithmetic with folding -------------------------------------------------------------
@@ -446,7 +446,7 @@ class Emitter:
             w = min(j * nwin // len(at), nwin - 1)
             if "PK_GLB_" in ln:
                 load[w] += 2
-            elif ln.startswith("OUT") or "IN_" in ln:
+            elif ln.startswith("OUT") or "IN_" in ln:  # (fillers are not in ``lines`` yet)
                 load[w] += 1
         import heapq
         heap = [(load[w], w) for w in range(nwin)]

@@ -64,6 +64,7 @@ struct brbd_model {
   // model-compiled kernels (brbd_spec.hpp), when the model's signature is registered
   const SpecEntry* spec = nullptr;
   double* d_ct[4] = {nullptr, nullptr, nullptr, nullptr};  // packed constant table per algorithm
+  bool prezeroed = false;  // brbd_model_outputs_prezeroed: derivative kernels skip structural zeros
   bool use_spec = true;  // BRBD_DISABLE_COMPILED=1 or brbd_model_use_compiled(m, 0): table-driven kernels
   bool use_lds = true;
   bool timing = false;
@@ -232,6 +233,7 @@ int launch_algo(brbd_model* m, int algo, KArgs& A, int layout, hipStream_t strea
   int variant = 0;
   if (sk) {
     if (algo == BRBD_ALGO_FK_JAC) variant = (A.out ? 1 : 0) | (A.out2 ? 2 : 0);
+    else if (algo == BRBD_ALGO_RNEA_DERIV) variant = m->prezeroed ? 1 : 0;
     else variant = 0;
     // buffer ranges: every matrix must span less than 4 GiB (32-bit byte offsets)
     const int64_t nn = (int64_t)F.nv * F.nv;
@@ -669,9 +671,11 @@ int brbd_rnea_derivatives(brbd_model* m, int64_t B, const double* q, int64_t ldq
   HIP_TRY(hipMemcpyAsync(da_, a, na_ * 8, hipMemcpyHostToDevice, s));
   // outputs with caller padding: preserve it
   const int64_t tight_nn = layout == BRBD_BATCH_MAJOR ? B : nn, tight_nv = layout == BRBD_BATCH_MAJOR ? B : F.nv;
-  if (lddq != tight_nn) HIP_TRY(hipMemcpyAsync(p1, dtau_dq, n1 * 8, hipMemcpyHostToDevice, s));
-  if (lddv != tight_nn) HIP_TRY(hipMemcpyAsync(p2, dtau_dv, n2 * 8, hipMemcpyHostToDevice, s));
-  if (p3 && ldda != tight_nn) HIP_TRY(hipMemcpyAsync(p3, dtau_da, n3 * 8, hipMemcpyHostToDevice, s));
+  // (and, under the prezeroed contract, the zeros the kernel will not write)
+  const bool pz = m->prezeroed;
+  if (pz || lddq != tight_nn) HIP_TRY(hipMemcpyAsync(p1, dtau_dq, n1 * 8, hipMemcpyHostToDevice, s));
+  if (pz || lddv != tight_nn) HIP_TRY(hipMemcpyAsync(p2, dtau_dv, n2 * 8, hipMemcpyHostToDevice, s));
+  if (p3 && (pz || ldda != tight_nn)) HIP_TRY(hipMemcpyAsync(p3, dtau_da, n3 * 8, hipMemcpyHostToDevice, s));
   if (p4 && ldtau != tight_nv) HIP_TRY(hipMemcpyAsync(p4, tau, n4 * 8, hipMemcpyHostToDevice, s));
   if ((rc = run(dq_, dv_, da_, p1, p2, p3, p4))) return rc;
   HIP_TRY(hipMemcpyAsync(dtau_dq, p1, n1 * 8, hipMemcpyDeviceToHost, s));
@@ -713,6 +717,12 @@ const char* brbd_model_compiled_kernels(const brbd_model* m) {
 int brbd_model_use_compiled(brbd_model* m, int enabled) {
   if (!m) return fail(BRBD_ERR_INVALID_ARGUMENT, "model handle is NULL");
   m->use_spec = enabled != 0;
+  return BRBD_OK;
+}
+
+int brbd_model_outputs_prezeroed(brbd_model* m, int enabled) {
+  if (!m) return fail(BRBD_ERR_INVALID_ARGUMENT, "model handle is NULL");
+  m->prezeroed = enabled != 0;
   return BRBD_OK;
 }
 

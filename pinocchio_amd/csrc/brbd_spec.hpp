@@ -134,6 +134,11 @@ DI void spec_sincos(double x, double& so, double& co) {
 #define OUT2(k, val) do { if (WANT & 2) mo2.put(k, ldo28, val); } while (0)
 #define OUT3(k, val) do { if (WANT & 4) mo3.put(k, ldo38, val); } while (0)
 #define OUT4(k, val) do { if (WANT & 8) mo4.put(k, ldo48, val); } while (0)
+// structural zeros of the derivative matrices: only in the kernels that do not assume that the
+// caller zeroed the outputs (WANT bit 4), as the reference does (rnea-derivatives.hpp:104-106)
+#define OUTZ(k) do { if ((WANT & 17) == 17) mo.put(k, ldo8, 0.0); } while (0)
+#define OUT2Z(k) do { if ((WANT & 18) == 18) mo2.put(k, ldo28, 0.0); } while (0)
+#define OUT3Z(k) do { if ((WANT & 20) == 20) mo3.put(k, ldo38, 0.0); } while (0)
 #define SINCOS(a, s, c) spec_sincos(a, s, c)
 #define RSQRT(a) rsqrt(a)
 #define RCP(a) (1.0 / (a))

@@ -255,20 +255,28 @@ def forwardKinematics(pool: ModelPool, q, device: Optional[int] = None):
     return oMi
 
 
-def computeRNEADerivatives(pool: ModelPool, q, v, a, want_tau: bool = False, device: Optional[int] = None):
+def computeRNEADerivatives(pool: ModelPool, q, v, a, want_tau: bool = False, device: Optional[int] = None,
+                           out=None):
     """Batched ``computeRNEADerivatives`` (algorithm/rnea-derivatives.hxx:472-541): returns
     (dtau_dq, dtau_dv, dtau_da), each (nv*nv, B) with per-instance column-major nv x nv blocks;
-    dtau_da holds the upper triangle of M like the reference."""
+    dtau_da holds the upper triangle of M like the reference.  ``out`` = (dtau_dq, dtau_dv,
+    dtau_da) already ZEROED by the caller selects the reference's contract
+    (rnea-derivatives.hpp:104-106): they are filled in place and structural zeros are not
+    rewritten."""
     m = pool.getModel(0)
     aq = _describe(q, m.nq, "q")
     av, aa = _describe(v, m.nv, "v", aq.layout), _describe(a, m.nv, "a", aq.layout)
     a0 = _same([aq, av, aa])
     nn = m.nv * m.nv
-    outs = [_alloc_like(q, a0, nn) for _ in range(3)]
-    d = [_describe(o, nn, "d") for o in outs]
+    outs = list(out) if out is not None else [_alloc_like(q, a0, nn) for _ in range(3)]
+    d = [_describe(o, nn, "d", aq.layout) for o in outs]
+    _same([aq] + d)
+    if out is not None and any(x.keep is not o for x, o in zip(d, outs)):
+        raise BrbdInvalidArgument("out matrices must be usable in place (float64, ordered like q)")
     tau = _alloc_like(q, a0, m.nv) if want_tau else None
     at = _describe(tau, m.nv, "tau") if want_tau else None
     dm = pool.device_model(_device_of(a0, device))
+    dm.outputs_prezeroed(out is not None)
     capi.check(capi.lib().brbd_rnea_derivatives(
         dm.handle, a0.B, aq.ptr, aq.ld, av.ptr, av.ld, aa.ptr, aa.ld, d[0].ptr, d[0].ld, d[1].ptr, d[1].ld,
         d[2].ptr, d[2].ld, at.ptr if at else None, at.ld if at else 0, a0.layout, a0.space, _stream(a0)))

@@ -49,11 +49,28 @@ def test_generated_derivative_bodies_match_oracle(model, dense):
     q, v, a = inputs(model, 6, 4)
     nn = model.nv * model.nv
     k = C.CpuKernel(mv, "deriv", reg_budget=8, lds_budget=24)
-    assert k.kernel.text.count("OUT(") == nn and k.kernel.text.count("OUT2(") == nn
-    assert k.kernel.text.count("OUT3(") == nn and k.kernel.text.count("OUT4(") == model.nv
+    t = k.kernel.text
+    assert t.count("OUT(") + t.count("OUTZ(") == nn and t.count("OUT2(") + t.count("OUT2Z(") == nn
+    assert t.count("OUT3(") + t.count("OUT3Z(") == nn and t.count("OUT4(") == model.nv
     dq, dv, da, tau = k.run(q, v, a, (nn, nn, nn, model.nv))
     rq, rv, ra, rt = oracle.Oracle(model).rnea_derivatives(q, v, a)
     for x, r in ((dq, rq), (dv, rv), (da, ra), (tau, rt)):
+        assert np.abs(x - r).max() / max(1.0, np.abs(r).max()) < 1e-12
+
+
+def test_derivative_body_under_the_prezeroed_contract():
+    """Without the structural zeros (rnea-derivatives.hpp:104-106: the caller zeroes the outputs)
+    the body writes only coupled entries; on zeroed outputs the result is the same."""
+    model = S.quadruped()
+    mv = joints.ModelView(model)
+    q, v, a = inputs(model, 5, 9)
+    nn = model.nv * model.nv
+    k = C.CpuKernel(mv, "deriv", skip_zeros=True)
+    nz = sum(k.kernel.text.count(m) for m in ("OUTZ(", "OUT2Z(", "OUT3Z("))
+    assert nz == 408 and k.kernel.text.count("OUT(") == 324 - 108   # 4 legs x 3 other legs x 3 x 3
+    got = k.run(q, v, a, (nn, nn, nn, model.nv))   # (CpuKernel.run starts from zeroed outputs)
+    ref = oracle.Oracle(model).rnea_derivatives(q, v, a)
+    for x, r in zip(got, ref):
         assert np.abs(x - r).max() / max(1.0, np.abs(r).max()) < 1e-12
 
 

@@ -370,6 +370,48 @@ def test_kernel_selection_pattern_dense_table(name):
     pool.release()
 
 
+@pytest.mark.parametrize("order", ["F", "C"])
+def test_derivatives_prezeroed_contract(torch_mod, order):
+    """brbd_model_outputs_prezeroed(1): the reference's contract (rnea-derivatives.hpp:104-106).
+    On zeroed outputs the result equals the default mode's; entries of unrelated branches are not
+    written at all (a NaN planted there survives); host and device memory."""
+    torch = torch_mod
+    model = S.quadruped()
+    pool = parallel.ModelPool(model, 1)
+    assert pool.device_model(0).compiled_kernels() == "quadruped_p"
+    B, nv = 200, model.nv
+    q, v, a = inputs(model, B, 21)
+    ref = oracle.Oracle(model).rnea_derivatives(q, v, a)
+    qq, vv, aa = (np.asarray(x, order=order) for x in (q, v, a))
+    outs = [np.zeros((nv * nv, B), order=order) for _ in range(3)]
+    r = parallel.computeRNEADerivatives(pool, qq, vv, aa, out=outs)
+    assert r[0] is outs[0]
+    for x, y in zip(outs, ref[:3]):
+        assert _mat_rel(x, y) < TOL_DERIV
+    # device memory, a NaN in a structurally zero entry: joint 2 (first leg) x joint 5 (second leg)
+    dev = torch.device("cuda", 0)
+    def put(x):
+        t = torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+        return t if order == "C" else torch.from_numpy(np.ascontiguousarray(x.T)).to(dev).t()
+    qd, vd, ad = put(q), put(v), put(a)
+    outd = [put(np.zeros((nv * nv, B))) for _ in range(3)]
+    row, col = model.idx_vs[2], model.idx_vs[5]
+    for o in outd:
+        o[col * nv + row, :] = float("nan")
+    parallel.computeRNEADerivatives(pool, qd, vd, ad, out=outd)
+    torch.cuda.synchronize()
+    for o, y in zip(outd, ref[:3]):
+        got = o.cpu().numpy()
+        assert np.isnan(got[col * nv + row]).all()
+        got[col * nv + row] = 0.0
+        assert _mat_rel(got, y) < TOL_DERIV
+    # back to the default contract: everything is written again
+    d2 = parallel.computeRNEADerivatives(pool, qd, vd, ad)
+    torch.cuda.synchronize()
+    assert _mat_rel(d2[0].cpu().numpy(), ref[0]) < TOL_DERIV
+    pool.release()
+
+
 def test_unregistered_model_uses_table_driven_kernels():
     pool = parallel.ModelPool(S.random_tree(100, 8), 1)
     assert pool.device_model(0).compiled_kernels() == ""

@@ -50,6 +50,11 @@ if "deriv" in which:
     q, v, a = inputs(m, B)
     t = timed(dm, capi.ALGO_RNEA_DERIV, lambda: parallel.computeRNEADerivatives(pool, q, v, a), 5)
     byts = ((m.nq + 2 * m.nv) + 3 * m.nv * m.nv) * 8 * B
-    print(json.dumps({"config": "quadruped RNEA derivatives B=262144", "s_per_call": t, "evals_per_s": B / t,
-                      "GBps_algorithmic": byts / t / 1e9}))
+    print(json.dumps({"config": "quadruped RNEA derivatives B=262144", "kernels": dm.compiled_kernels(),
+                      "s_per_call": t, "evals_per_s": B / t, "GBps_algorithmic": byts / t / 1e9}))
+    # the reference's contract: outputs zeroed by the caller, structural zeros not rewritten
+    outs = [torch.zeros((m.nv * m.nv, B), dtype=torch.float64, device="cuda") for _ in range(3)]
+    t = timed(dm, capi.ALGO_RNEA_DERIV, lambda: parallel.computeRNEADerivatives(pool, q, v, a, out=outs), 5)
+    print(json.dumps({"config": "quadruped RNEA derivatives B=262144, outputs pre-zeroed by the caller",
+                      "s_per_call": t, "evals_per_s": B / t, "GBps_algorithmic": byts / t / 1e9}))
     pool.release()

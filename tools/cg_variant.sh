@@ -1,6 +1,7 @@
 #!/bin/bash
 # Build one experimental variant of the model-compiled kernels for $MODEL (pattern) into
-# gpurun_out/lib_<tag>.so and print its register usage.  Usage: tools/cg_variant.sh tag [ENV=...]
+# ab_libs/lib_<tag>.so and print its register usage.  Usage: tools/cg_variant.sh tag [ENV=...]
+# (EXTRA = extra hipcc flags, e.g. -DBRBD_SPEC_TRACE; ALGOS = which usage lines to print)
 set -e
 TAG=$1; shift
 MODEL=${MODEL:-simple_humanoid}
@@ -8,11 +9,10 @@ cd "$(dirname "$0")/.."
 D=/tmp/cgv_$TAG; rm -rf $D; mkdir -p $D/gen
 env "$@" python -m pinocchio_amd.codegen.build --out $D/gen --models $MODEL --variants p 2>/dev/null
 FLAGS="$EXTRA -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-unused-variable -Wno-unused-but-set-variable -I pinocchio_amd/csrc"
-sed -i 's#"../brbd_spec.hpp"#"brbd_spec.hpp"#' $D/gen/spec_${MODEL}_p.hip
-( /opt/rocm/bin/hipcc $FLAGS -c -o $D/spec.o $D/gen/spec_${MODEL}_p.hip -Rpass-analysis=kernel-resource-usage 2>&1 | grep -E "Function Name|VGPRs:|AGPRs|Scratch|SGPRs Spill|VGPRs Spill" | grep -A5 "k_rneaIL\|k_abaIL\|k_derivIL" | sed 's/.*remark: *//;s/\[-Rpass.*//' | tr "\n" " " | sed "s/Function Name: _ZN4brbd22spec_${MODEL}_p/\n/g"; echo ) &
-sed -e 's#"gen/registry.inc"#"'$D'/gen/registry.inc"#' -e 's#"../../include/brbd.h"#"brbd.h"#' pinocchio_amd/csrc/brbd_capi.hip > $D/capi.hip
-/opt/rocm/bin/hipcc $FLAGS -I include -c -o $D/capi.o $D/capi.hip 2>&1 | grep -E "error"  &
-wait
+sed -i 's#"../brbd_spec.hpp"#"brbd_spec.hpp"#' $D/gen/spec_*.hip
+sed -e 's#"gen/registry.inc"#"'$D'/gen/registry.inc"#' -e 's#"../../include/brbd.h"#"brbd.h"#' pinocchio_amd/csrc/brbd_capi.hip > $D/gen/spec_capi.hip
+ls $D/gen/spec_*.hip | xargs -P 8 -I{} sh -c "/opt/rocm/bin/hipcc $FLAGS -I include -I $D/gen -c -o {}.o {} -Rpass-analysis=kernel-resource-usage 2> {}.usage || { grep error {}.usage; exit 255; }"
+cat $D/gen/*.usage | grep -E "Function Name|VGPRs:|AGPRs|Scratch|SGPRs Spill|VGPRs Spill" | grep -A5 "k_rneaIL\|k_abaIL\|k_derivIL" | sed 's/.*remark: *//;s/\[-Rpass.*//' | tr "\n" " " | sed "s/Function Name: _ZN4brbd[0-9]*spec_${MODEL}_p/\n/g"; echo
 mkdir -p ab_libs
-/opt/rocm/bin/hipcc $FLAGS -shared -o ab_libs/lib_$TAG.so $D/capi.o $D/spec.o 2>/dev/null
+/opt/rocm/bin/hipcc $FLAGS -shared -o ab_libs/lib_$TAG.so $D/gen/*.o 2>/dev/null
 echo "built ab_libs/lib_$TAG.so"

@@ -110,6 +110,17 @@ int brbd_device_count(void);
  * multibody/pool/model.hpp:41-46).  Rejects unsupported joint types with
  * BRBD_ERR_UNSUPPORTED, malformed tables with BRBD_ERR_INVALID_ARGUMENT. */
 int brbd_model_create(const brbd_model_desc* desc, int device, brbd_model** out);
+
+/* What the table-driven kernels see (host only, no device needed; diagnostics and tests).
+ * Unaligned joints (joint-revolute-unaligned.hpp:667-708, joint-prismatic-unaligned.hpp) are
+ * canonicalised by the flattener: with Q a rotation taking e_z to the axis, the joint becomes an
+ * RZ / PZ joint in the frame (described frame) * Q; its body inertia and its children's placements
+ * are re-expressed in that frame.  q, v, a, tau, the world-frame Jacobian and the derivatives are
+ * unchanged; forwardKinematics' oMi is the canonical one times `post` (= Q^T).  Outputs, each
+ * caller-allocated: jtype[njoints]; placement[njoints][12] and inertia[njoints][10] laid out like
+ * brbd_model_desc; post[njoints][9] row-major (identity for joints left as described). */
+int brbd_model_canonical_form(const brbd_model_desc* desc, int32_t* jtype, double* placement,
+                              double* inertia, double* post);
 int brbd_model_destroy(brbd_model* m);
 int brbd_model_dims(const brbd_model* m, int32_t* njoints, int32_t* nq, int32_t* nv);
 

@@ -34,7 +34,7 @@ SYMBOLS = (
     "brbd_model_create", "brbd_model_destroy", "brbd_model_dims", "brbd_workspace_bytes",
     "brbd_rnea", "brbd_aba", "brbd_fk_jacobians", "brbd_rnea_derivatives",
     "brbd_transpose_to_batch_major", "brbd_transpose_to_instance_major",
-    "brbd_set_timing", "brbd_kernel_time", "brbd_model_compiled_kernels", "brbd_model_use_compiled", "brbd_model_outputs_prezeroed",
+    "brbd_set_timing", "brbd_kernel_time", "brbd_model_compiled_kernels", "brbd_model_use_compiled", "brbd_model_outputs_prezeroed", "brbd_model_canonical_form",
 )
 
 
@@ -56,6 +56,25 @@ class BrbdRuntimeError(RuntimeError):
 
 
 _lib = None
+
+
+def canonical_form(model):
+    """(canonical Model, post[njoints, 3, 3]) as the table-driven kernels see ``model``: unaligned
+    joints turned into RZ / PZ joints of a rotated joint frame (include/brbd.h:
+    brbd_model_canonical_form).  Host only."""
+    import numpy as np
+    from . import model as M
+    desc, keep = model.to_desc()
+    n = model.njoints
+    jt = np.zeros(n, dtype=np.int32)
+    P, Y, post = np.zeros((n, 12)), np.zeros((n, 10)), np.zeros((n, 9))
+    check(lib().brbd_model_canonical_form(ctypes.byref(desc), jt.ctypes.data, P.ctypes.data, Y.ctypes.data,
+                                          post.ctypes.data))
+    t = model.tables()
+    t["jtype"], t["placement"], t["inertia"] = jt.tolist(), P.tolist(), Y.tolist()
+    out = {k: (v.tolist() if isinstance(v, np.ndarray) else v) for k, v in t.items()}
+    import json
+    return M.Model.from_json(json.dumps(out)), post.reshape(n, 3, 3)
 
 
 def lib():
@@ -113,6 +132,8 @@ def lib():
     L.brbd_model_compiled_kernels.argtypes = [vp]
     L.brbd_model_use_compiled.restype = ci
     L.brbd_model_use_compiled.argtypes = [vp, ci]
+    L.brbd_model_canonical_form.restype = ci
+    L.brbd_model_canonical_form.argtypes = [vp, vp, vp, vp, vp]
     L.brbd_model_outputs_prezeroed.restype = ci
     L.brbd_model_outputs_prezeroed.argtypes = [vp, ci]
     L.brbd_set_timing.restype = ci

@@ -78,7 +78,7 @@ namespace {
 // tree, joint kinds, and per constant one of 0 / 1 / m(-1) / g(eneric); `dense`: geometry and
 // inertias all generic (armature and gravity keep their pattern).
 double model_constant(const FlatModel& F, int joint, int field, int index) {
-  const JointConst& jc = F.tab[joint];
+  const JointConst& jc = F.tab_desc[joint];  // (as described: the compiled kernels know every joint kind)
   switch (field) {
     case SF_R: return jc.R[index];
     case SF_T: return jc.t[index];
@@ -92,9 +92,9 @@ double model_constant(const FlatModel& F, int joint, int field, int index) {
 }
 std::string model_signature(const FlatModel& F, bool dense) {
   std::string s = "n" + std::to_string(F.njoints) + ";p";
-  for (int i = 1; i < F.njoints; ++i) s += (i > 1 ? "," : "") + std::to_string(F.tab[i].parent);
+  for (int i = 1; i < F.njoints; ++i) s += (i > 1 ? "," : "") + std::to_string(F.tab_desc[i].parent);
   s += ";j";
-  for (int i = 1; i < F.njoints; ++i) s += (i > 1 ? "," : "") + std::to_string(F.tab[i].jtype);
+  for (int i = 1; i < F.njoints; ++i) s += (i > 1 ? "," : "") + std::to_string(F.tab_desc[i].jtype);
   s += ";";
   auto put = [&](double x, bool keep) {
     char c = x == 0.0 ? '0' : (x == 1.0 ? '1' : (x == -1.0 ? 'm' : 'g'));
@@ -102,7 +102,7 @@ std::string model_signature(const FlatModel& F, bool dense) {
   };
   for (int k = 0; k < 3; ++k) put(F.gravity[k], true);
   for (int i = 1; i < F.njoints; ++i) {
-    const JointConst& jc = F.tab[i];
+    const JointConst& jc = F.tab_desc[i];
     for (int k = 0; k < 9; ++k) put(jc.R[k], false);
     for (int k = 0; k < 3; ++k) put(jc.t[k], false);
     put(jc.m, false);
@@ -368,6 +368,30 @@ int brbd_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
+}
+
+int brbd_model_canonical_form(const brbd_model_desc* desc, int32_t* jtype, double* placement,
+                              double* inertia, double* post) {
+  if (!jtype || !placement || !inertia || !post) return fail(BRBD_ERR_INVALID_ARGUMENT, "output table is NULL");
+  FlatModel F;
+  int status = BRBD_OK;
+  const std::string err = flatten(desc, &F, &status);
+  if (status != BRBD_OK) return fail(status, err);
+  for (int i = 0; i < F.njoints; ++i) {
+    const JointConst& jc = F.tab[i];
+    const bool canon = i > 0 && jc.jtype != F.tab_desc[i].jtype;
+    jtype[i] = jc.jtype;
+    double* P = placement + 12 * (size_t)i;
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) P[3 * c + r] = i ? jc.R[3 * r + c] : (r == c ? 1.0 : 0.0);
+    for (int k = 0; k < 3; ++k) P[9 + k] = jc.t[k];
+    double* Y = inertia + 10 * (size_t)i;
+    Y[0] = jc.m;
+    for (int k = 0; k < 3; ++k) Y[1 + k] = jc.c[k];
+    for (int k = 0; k < 6; ++k) Y[4 + k] = jc.I[k];
+    for (int k = 0; k < 9; ++k) post[9 * (size_t)i + k] = canon ? jc.post[k] : ((k % 4 == 0) ? 1.0 : 0.0);
+  }
+  return BRBD_OK;
 }
 
 int brbd_model_create(const brbd_model_desc* desc, int device, brbd_model** out) {

@@ -21,7 +21,7 @@ enum : int {
 };
 
 // ---- per-joint constant record (BatchModel table row) -----------------------------------------
-// 288 bytes, 16-byte aligned so the scalar unit can fetch it with s_load_dwordx8/x16.
+// 368 bytes, 16-byte aligned so the scalar unit can fetch it with s_load_dwordx8/x16.
 struct alignas(16) JointConst {
   double R[9];    // jointPlacement rotation, row-major
   double t[3];    // jointPlacement translation
@@ -30,6 +30,7 @@ struct alignas(16) JointConst {
   double I[6];    //          Symmetric3 (xx,xy,yy,xz,yz,zz) about the COM
   double arm[6];  // armature of this joint's dofs
   double axis[3]; // unit axis (unaligned kinds)
+  double post[9]; // canonicalised unaligned joints: oMi = (oMi of the canonical frame) * post (row-major)
   int32_t jtype, parent, idx_q, idx_v;
   int32_t hand_off;  // ABA: first slot of this joint's pass2->pass3 hand-off record
   int32_t comp;      // 1-dof aligned kinds: index of the non-zero component of S (0..5)
@@ -50,7 +51,7 @@ DI const T BRBD_CONSTANT* as_constant(const T* p) {
 DI void load_joint(const JointConst* tab, int i, JointConst& o) {
   const JointConst BRBD_CONSTANT* t = as_constant(tab) + i;
 #pragma unroll
-  for (int k = 0; k < 9; ++k) o.R[k] = t->R[k];
+  for (int k = 0; k < 9; ++k) { o.R[k] = t->R[k]; o.post[k] = t->post[k]; }
 #pragma unroll
   for (int k = 0; k < 3; ++k) { o.t[k] = t->t[k]; o.c[k] = t->c[k]; o.axis[k] = t->axis[k]; }
   o.m = t->m;
@@ -81,7 +82,8 @@ enum : int {
   F_CARRY_REGS = 32,   // backward visit: hand the contribution to the parent in registers
                        //   (parent has exactly one child) instead of read-modify-write
   F_CARRY_IN = 64,     // BWD: exactly one child: its contribution is in the carry registers
-  F_MULTI = 128        // BWD: >= 2 children: accumulator slot already holds own + children
+  F_MULTI = 128,       // BWD: >= 2 children: accumulator slot already holds own + children
+  F_POST = 256         // FK output: the joint frame was canonicalised (unaligned axis): oMi = oMi' * post
 };
 DI int op_own_bslot(int flags) { return flags >> 16; }
 DI Op load_op(const Op* prog, int s) {

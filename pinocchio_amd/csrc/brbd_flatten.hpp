@@ -9,6 +9,8 @@
 // accumulations (f[parent] += ..., oYaba[parent] += ...) happen in exactly the order of the
 // reference's `for (i = njoints-1; i > 0; --i)` loops (rnea.hxx:152-155, aba.hxx:276-279).
 #pragma once
+#include <cmath>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -25,7 +27,8 @@ struct FlatModel {
   int maxdepth = 1, maxbranch = 1;
   int hand_total = 0;  // doubles per lane of ABA hand-off records
   double gravity[3] = {0, 0, -9.81};
-  std::vector<JointConst> tab;
+  std::vector<JointConst> tab;       // what the table-driven kernels read (unaligned joints canonicalised)
+  std::vector<JointConst> tab_desc;  // as described (signature / constants of the model-compiled kernels)
   std::vector<Op> prog;   // FWD/BWD program (RNEA, ABA passes 1+2)
   std::vector<Op> prog3;  // FWD-only program (ABA pass 3, FK/Jacobians)
   bool depth_first = true;  // subtrees are contiguous index ranges (needed by RNEA derivatives)
@@ -37,6 +40,15 @@ struct FlatModel {
   int ws_aba() const { return stack_aba() + hand_total; }
   int ws_fkjac() const { return maxbranch * 12; }
 };
+
+// Unaligned joints (joint-revolute-unaligned.hpp:667-708, joint-prismatic-unaligned.hpp) run on the
+// kernels of the aligned ones.  With Q a rotation that takes e_z to the axis u, the joint transform
+// is M(q) = Q M_z(q) Q^T (rotation about / translation along z), so the joint is an RZ / PZ joint
+// whose frame is the described one times Q: placement' = placement Q, the body inertia and the
+// children's placements are re-expressed in that frame (Q^T . Y, Q^T . placement_child), q / v / a /
+// tau are the same numbers.  RNEA, ABA, the world-frame Jacobian and the derivatives do not
+// depend on the choice of joint frame; forwardKinematics' oMi does: oMi = oMi' Q^T (F_POST).
+inline std::string canonicalise_unaligned(struct FlatModel& M, const std::vector<std::vector<int>>& children);
 
 // returns "" on success, else an error message; *status gets the BRBD_ERR_* code
 inline std::string flatten(const brbd_model_desc* d, FlatModel* out, int* status) {
@@ -64,10 +76,8 @@ inline std::string flatten(const brbd_model_desc* d, FlatModel* out, int* status
     if (p < 0 || p >= i)
       return "parents[" + std::to_string(i) + "] must satisfy 0 <= parent < joint index";
     if (jt < 0 || jt >= BRBD_JOINT_TYPE_COUNT) return "jtype[" + std::to_string(i) + "] is not a brbd_joint_type";
-    if (jt == BRBD_JOINT_REVOLUTE_UNALIGNED || jt == BRBD_JOINT_PRISMATIC_UNALIGNED) {
-      *status = BRBD_ERR_UNSUPPORTED;
-      return "joint " + std::to_string(i) + ": unaligned joint kinds are not supported by the HIP kernels yet";
-    }
+    if ((jt == BRBD_JOINT_REVOLUTE_UNALIGNED || jt == BRBD_JOINT_PRISMATIC_UNALIGNED) && !d->axis)
+      return "joint " + std::to_string(i) + " is unaligned but the description has no axis table";
     const int nqj = kJointNq[jt], nvj = kJointNv[jt];
     if (d->idx_q[i] < 0 || d->idx_q[i] + nqj > d->nq) return "idx_q[" + std::to_string(i) + "] out of range";
     if (d->idx_v[i] < 0 || d->idx_v[i] + nvj > d->nv) return "idx_v[" + std::to_string(i) + "] out of range";
@@ -109,6 +119,9 @@ inline std::string flatten(const brbd_model_desc* d, FlatModel* out, int* status
   for (char c : vcover)
     if (!c) return "idx_v ranges do not cover nv";
   M.hand_total = hand;
+  M.tab_desc = M.tab;
+  std::string err = canonicalise_unaligned(M, children);
+  if (!err.empty()) return err;
 
   // depth, branch slots
   std::vector<int> depth(n, -1), bslot(n, -1);
@@ -152,6 +165,7 @@ inline std::string flatten(const brbd_model_desc* d, FlatModel* out, int* status
       fl |= F_LEAF;
       if (p != 0 && children[p].size() == 1) fl |= F_CARRY_REGS;
     }
+    if (M.tab_desc[i].jtype != M.tab[i].jtype) fl |= F_POST;
     fl |= bslot[i] << 16;
     op.flags = fl;
     M.prog.push_back(op);
@@ -211,6 +225,57 @@ inline std::string flatten(const brbd_model_desc* d, FlatModel* out, int* status
   for (int i = 1; i < n; ++i)
     M.nv_subtree[i] = d->idx_v[last[i]] + kJointNv[d->jtype[last[i]]] - d->idx_v[i];
   *status = BRBD_OK;
+  return "";
+}
+
+inline std::string canonicalise_unaligned(FlatModel& M, const std::vector<std::vector<int>>& children) {
+  auto mul = [](const double* A, const double* B, double* C) {  // row-major 3x3
+    double T[9];
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) T[3 * r + c] = A[3 * r] * B[c] + A[3 * r + 1] * B[3 + c] + A[3 * r + 2] * B[6 + c];
+    for (int k = 0; k < 9; ++k) C[k] = T[k];
+  };
+  for (int i = 1; i < M.njoints; ++i) {
+    JointConst& jc = M.tab[i];
+    const bool ru = jc.jtype == BRBD_JOINT_REVOLUTE_UNALIGNED, pu = jc.jtype == BRBD_JOINT_PRISMATIC_UNALIGNED;
+    if (!ru && !pu) continue;
+    double u[3] = {jc.axis[0], jc.axis[1], jc.axis[2]};
+    const double nrm = std::sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+    if (!(nrm > 0.0)) return "joint " + std::to_string(i) + ": unaligned joint with a zero axis";
+    for (int k = 0; k < 3; ++k) u[k] /= nrm;
+    // right-handed orthonormal basis (a, b, u): a = u x e_min normalised, b = u x a
+    int kmin = 0;
+    for (int k = 1; k < 3; ++k)
+      if (std::fabs(u[k]) < std::fabs(u[kmin])) kmin = k;
+    double e[3] = {0, 0, 0}, a[3], b[3];
+    e[kmin] = 1.0;
+    a[0] = u[1] * e[2] - u[2] * e[1]; a[1] = u[2] * e[0] - u[0] * e[2]; a[2] = u[0] * e[1] - u[1] * e[0];
+    const double na = std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+    for (int k = 0; k < 3; ++k) a[k] /= na;
+    b[0] = u[1] * a[2] - u[2] * a[1]; b[1] = u[2] * a[0] - u[0] * a[2]; b[2] = u[0] * a[1] - u[1] * a[0];
+    double Q[9], Qt[9];
+    for (int r = 0; r < 3; ++r) { Q[3 * r] = a[r]; Q[3 * r + 1] = b[r]; Q[3 * r + 2] = u[r]; }
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) Qt[3 * r + c] = Q[3 * c + r];
+    mul(jc.R, Q, jc.R);  // placement' = placement Q
+    // inertia in the new frame: c' = Q^T c, I' = Q^T I Q
+    const double c0[3] = {jc.c[0], jc.c[1], jc.c[2]};
+    for (int r = 0; r < 3; ++r) jc.c[r] = Qt[3 * r] * c0[0] + Qt[3 * r + 1] * c0[1] + Qt[3 * r + 2] * c0[2];
+    double I3[9] = {jc.I[0], jc.I[1], jc.I[3], jc.I[1], jc.I[2], jc.I[4], jc.I[3], jc.I[4], jc.I[5]}, T[9];
+    mul(Qt, I3, T);
+    mul(T, Q, I3);
+    jc.I[0] = I3[0]; jc.I[1] = 0.5 * (I3[1] + I3[3]); jc.I[2] = I3[4];
+    jc.I[3] = 0.5 * (I3[2] + I3[6]); jc.I[4] = 0.5 * (I3[5] + I3[7]); jc.I[5] = I3[8];
+    for (int k = 0; k < 9; ++k) jc.post[k] = Qt[k];
+    jc.jtype = ru ? BRBD_JOINT_RZ : BRBD_JOINT_PZ;
+    jc.comp = ru ? 5 : 2;
+    for (int ch : children[i]) {  // placement_child' = Q^T . placement_child
+      JointConst& cc = M.tab[ch];
+      mul(Qt, cc.R, cc.R);
+      const double t0[3] = {cc.t[0], cc.t[1], cc.t[2]};
+      for (int r = 0; r < 3; ++r) cc.t[r] = Qt[3 * r] * t0[0] + Qt[3 * r + 1] * t0[1] + Qt[3 * r + 2] * t0[2];
+    }
+  }
   return "";
 }
 

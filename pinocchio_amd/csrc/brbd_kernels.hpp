@@ -1005,10 +1005,19 @@ DI void fkjac_step(const KArgs& A, const Op op, Stack& S, const MatT& q, const M
   }
   if (wantM) {
     const int o = 12 * op.joint;
+    if (fl & F_POST) {  // back from the canonical joint frame to the described one (brbd_flatten.hpp)
+      double Ro[9];
+      rot_mul(st.R, jc.post, Ro);
 #pragma unroll
-    for (int r = 0; r < 3; ++r)
+      for (int r = 0; r < 3; ++r)
 #pragma unroll
-      for (int c = 0; c < 3; ++c) Mout.put(o + 3 * c + r, st.R[3 * r + c]);  // column-major rotation
+        for (int c = 0; c < 3; ++c) Mout.put(o + 3 * c + r, Ro[3 * r + c]);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) Mout.put(o + 3 * c + r, st.R[3 * r + c]);  // column-major rotation
+    }
     Mout.put(o + 9, st.t[0]); Mout.put(o + 10, st.t[1]); Mout.put(o + 11, st.t[2]);
   }
   if (wantJ) {

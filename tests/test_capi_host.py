@@ -51,12 +51,51 @@ def test_flattener_rejects_bad_tables():
     assert rc == capi.BRBD_ERR_INVALID_ARGUMENT
 
 
-def test_unsupported_joint_kind_is_rejected_at_flatten_time():
+def test_unaligned_joints_pass_the_flattener(have_gpu):
     m = M.Model("unaligned")
     m.addJoint(0, M.JOINT_REVOLUTE_UNALIGNED, np.eye(4), "j1", axis=[1, 1, 0])
     m.appendBodyToJoint(1, M.Inertia(1.0, [0, 0, 0.1], np.eye(3)))
-    rc, _, err = _create(m)
-    assert rc == capi.BRBD_ERR_UNSUPPORTED and "unaligned" in err
+    rc, h, err = _create(m)
+    assert rc == (capi.BRBD_OK if have_gpu else capi.BRBD_ERR_NO_DEVICE), err
+    # a zero axis cannot be canonicalised
+    d, keep = m.to_desc()
+    z = np.zeros((m.njoints, 3))
+    d.axis = z.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    out = ctypes.c_void_p()
+    assert capi.lib().brbd_model_create(ctypes.byref(d), 0, ctypes.byref(out)) == capi.BRBD_ERR_INVALID_ARGUMENT
+    assert "zero axis" in capi.lib().brbd_last_error().decode()
+
+
+def test_canonical_form_of_unaligned_joints_is_the_same_robot():
+    """The flattener turns unaligned joints into RZ / PZ joints of a rotated joint frame
+    (brbd_model_canonical_form).  The oracle, which knows unaligned joints natively
+    (joint-revolute-unaligned.hpp:667-708), must give the same RNEA / ABA / world Jacobians /
+    derivatives for both descriptions, and oMi = oMi_canonical * post."""
+    import oracle
+    from util import inputs
+    kinds = [M.JOINT_RX, M.JOINT_PY, M.JOINT_REVOLUTE_UNALIGNED, M.JOINT_PRISMATIC_UNALIGNED, M.JOINT_SPHERICAL,
+             M.JOINT_REVOLUTE_UNALIGNED, M.JOINT_RUBZ]
+    for seed in range(4):
+        m = S.random_tree(500 + seed, 10, kinds=kinds, root_kind=M.JOINT_FREEFLYER if seed % 2 else None)
+        assert any(t in (M.JOINT_REVOLUTE_UNALIGNED, M.JOINT_PRISMATIC_UNALIGNED) for t in m.jtypes[1:])
+        mc, post = capi.canonical_form(m)
+        assert not any(t in (M.JOINT_REVOLUTE_UNALIGNED, M.JOINT_PRISMATIC_UNALIGNED) for t in mc.jtypes[1:])
+        O, Oc = oracle.Oracle(m), oracle.Oracle(mc)
+        q, v, a = inputs(m, 6, seed)
+        tau = O.rnea(q, v, a)
+        assert np.abs(Oc.rnea(q, v, a) - tau).max() < 1e-11 * max(1.0, np.abs(tau).max())
+        assert np.abs(Oc.aba(q, v, tau) - a).max() < 1e-9
+        J, oMi = O.fk_jacobians(q)
+        Jc, oMic = Oc.fk_jacobians(q)
+        assert np.abs(J - Jc).max() < 1e-12
+        for i in range(1, m.njoints):
+            Rc = oMic[12 * i:12 * i + 9].T.reshape(-1, 3, 3).transpose(0, 2, 1)   # column-major -> (B, 3, 3)
+            R = oMi[12 * i:12 * i + 9].T.reshape(-1, 3, 3).transpose(0, 2, 1)
+            assert np.abs(Rc @ post[i] - R).max() < 1e-12
+            assert np.abs(oMic[12 * i + 9:12 * i + 12] - oMi[12 * i + 9:12 * i + 12]).max() < 1e-12
+        if m.is_depth_first():
+            for x, y in zip(O.rnea_derivatives(q, v, a), Oc.rnea_derivatives(q, v, a)):
+                assert np.abs(x - y).max() < 1e-10 * max(1.0, np.abs(x).max())
 
 
 def test_no_cpu_fallback_without_device(have_gpu):

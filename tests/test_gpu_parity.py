@@ -370,6 +370,21 @@ def test_kernel_selection_pattern_dense_table(name):
     pool.release()
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_unaligned_joints(seed):
+    """RevoluteUnaligned / PrismaticUnaligned (joint-revolute-unaligned.hpp:667-708): the flattener
+    canonicalises them onto the RZ / PZ code of the table-driven kernels; every algorithm, both
+    boundary layouts, against the oracle, which evaluates them natively."""
+    kinds = [M.JOINT_RX, M.JOINT_PY, M.JOINT_REVOLUTE_UNALIGNED, M.JOINT_PRISMATIC_UNALIGNED, M.JOINT_SPHERICAL,
+             M.JOINT_REVOLUTE_UNALIGNED, M.JOINT_RUBZ]
+    model = S.random_tree(500 + seed, 10, kinds=kinds, root_kind=M.JOINT_FREEFLYER if seed % 2 else None)
+    assert any(t in (M.JOINT_REVOLUTE_UNALIGNED, M.JOINT_PRISMATIC_UNALIGNED) for t in model.jtypes[1:])
+    pool = parallel.ModelPool(model, 1)
+    assert pool.device_model(0).compiled_kernels() == ""
+    _check_all(pool, model, oracle.Oracle(model))
+    pool.release()
+
+
 @pytest.mark.parametrize("order", ["F", "C"])
 def test_derivatives_prezeroed_contract(torch_mod, order):
     """brbd_model_outputs_prezeroed(1): the reference's contract (rnea-derivatives.hpp:104-106).

@@ -204,7 +204,10 @@ int brbd_model_outputs_prezeroed(brbd_model* m, int enabled);
 /* Kernel timing for the roofline (bench.py): with timing enabled every kernel launch of the
  * engine is bracketed by hipEvents recorded on the launch stream.  brbd_kernel_time() waits for
  * the recorded launches of `algo` (enum brbd_algo), returns how many there were and their summed
- * device time in milliseconds, and forgets them. */
+ * device time in milliseconds, and forgets them.  enabled = 2 ("chained"): the event that closes
+ * one launch also opens the next launch of the same handle on the same stream, i.e. one event
+ * per launch instead of two (an event costs the stream about 3 us); a launch's time then includes
+ * the gap to its predecessor, and whatever else the caller put on the stream in between. */
 int brbd_set_timing(brbd_model* m, int enabled);
 int brbd_kernel_time(brbd_model* m, int algo, int32_t* launches, double* total_ms);
 

@@ -198,8 +198,10 @@ class DeviceModel:
         """Derivative outputs under the reference's contract (caller zeroed them): see include/brbd.h"""
         check(lib().brbd_model_outputs_prezeroed(self.handle, 1 if on else 0))
 
-    def set_timing(self, on: bool):
-        check(lib().brbd_set_timing(self.handle, 1 if on else 0))
+    def set_timing(self, on: bool, chained: bool = False):
+        """hipEvents around every kernel launch; ``chained``: one shared event between consecutive
+        launches instead of two (include/brbd.h: brbd_set_timing)."""
+        check(lib().brbd_set_timing(self.handle, (2 if chained else 1) if on else 0))
 
     def kernel_time(self, algo: int):
         n = ctypes.c_int32(0)

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -39,8 +40,12 @@ int fail(int code, const std::string& msg) {
       return fail(BRBD_ERR_RUNTIME, std::string(#expr) + ": " + hipGetErrorString(e_));     \
   } while (0)
 
+struct Ev {  // a hipEvent shared by the launches it delimits
+  hipEvent_t e = nullptr;
+  ~Ev() { if (e) (void)hipEventDestroy(e); }
+};
 struct TimedLaunch {
-  hipEvent_t start, stop;
+  std::shared_ptr<Ev> start, stop;
 };
 
 }  // namespace
@@ -67,7 +72,9 @@ struct brbd_model {
   bool prezeroed = false;  // brbd_model_outputs_prezeroed: derivative kernels skip structural zeros
   bool use_spec = true;  // BRBD_DISABLE_COMPILED=1 or brbd_model_use_compiled(m, 0): table-driven kernels
   bool use_lds = true;
-  bool timing = false;
+  int timing = 0;  // 0 off, 1 two events per launch, 2 chained (one event per launch)
+  std::shared_ptr<Ev> last_stop;
+  hipStream_t last_stream = nullptr;
   std::vector<TimedLaunch> timed[4];
   std::mutex mu;
 };
@@ -201,17 +208,27 @@ struct Timer {
   bool on = false;
   int begin() {
     if (!m->timing) return BRBD_OK;
-    HIP_TRY(hipEventCreate(&t.start));
-    HIP_TRY(hipEventCreate(&t.stop));
-    HIP_TRY(hipEventRecord(t.start, s));
+    // chained timing (brbd_set_timing(m, 2)): the event that closed the previous launch of this
+    // handle on this stream opens this one: one event per launch instead of two
+    if (m->timing == 2 && m->last_stop && m->last_stream == s) {
+      t.start = m->last_stop;
+    } else {
+      t.start = std::make_shared<Ev>();
+      HIP_TRY(hipEventCreate(&t.start->e));
+      HIP_TRY(hipEventRecord(t.start->e, s));
+    }
+    t.stop = std::make_shared<Ev>();
+    HIP_TRY(hipEventCreate(&t.stop->e));
     on = true;
     return BRBD_OK;
   }
   int end() {
     if (!on) return BRBD_OK;
-    HIP_TRY(hipEventRecord(t.stop, s));
+    HIP_TRY(hipEventRecord(t.stop->e, s));
     std::lock_guard<std::mutex> g(m->mu);
     m->timed[algo].push_back(t);
+    m->last_stop = t.stop;
+    m->last_stream = s;
     return BRBD_OK;
   }
 };
@@ -455,11 +472,8 @@ int brbd_model_create(const brbd_model_desc* desc, int device, brbd_model** out)
 int brbd_model_destroy(brbd_model* m) {
   if (!m) return BRBD_OK;
   DevGuard dg(m->device);
-  for (auto& v : m->timed)
-    for (auto& t : v) {
-      (void)hipEventDestroy(t.start);
-      (void)hipEventDestroy(t.stop);
-    }
+  for (auto& v : m->timed) v.clear();  // (events are destroyed with their last holder)
+  m->last_stop.reset();
   if (m->d_tab) (void)hipFree(m->d_tab);
   if (m->d_prog) (void)hipFree(m->d_prog);
   if (m->d_prog3) (void)hipFree(m->d_prog3);
@@ -752,7 +766,11 @@ int brbd_model_outputs_prezeroed(brbd_model* m, int enabled) {
 
 int brbd_set_timing(brbd_model* m, int enabled) {
   if (!m) return fail(BRBD_ERR_INVALID_ARGUMENT, "model handle is NULL");
-  m->timing = enabled != 0;
+  m->timing = enabled == 2 ? 2 : (enabled != 0 ? 1 : 0);
+  {
+    std::lock_guard<std::mutex> g(m->mu);
+    m->last_stop.reset();
+  }
   return BRBD_OK;
 }
 
@@ -766,12 +784,10 @@ int brbd_kernel_time(brbd_model* m, int algo, int32_t* launches, double* total_m
   }
   double sum = 0.0;
   for (auto& t : v) {
-    HIP_TRY(hipEventSynchronize(t.stop));
+    HIP_TRY(hipEventSynchronize(t.stop->e));
     float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, t.start, t.stop));
+    HIP_TRY(hipEventElapsedTime(&ms, t.start->e, t.stop->e));
     sum += ms;
-    (void)hipEventDestroy(t.start);
-    (void)hipEventDestroy(t.stop);
   }
   if (launches) *launches = (int32_t)v.size();
   if (total_ms) *total_ms = sum;

@@ -51,7 +51,9 @@ enum brbd_joint_type {
   BRBD_JOINT_RUBX = 10, /* JointModelRUBX joint-revolute-unbounded.hpp (nq=2: cos,sin) */
   BRBD_JOINT_RUBY = 11,
   BRBD_JOINT_RUBZ = 12,
-  BRBD_JOINT_TYPE_COUNT = 13
+  /* joint-revolute-unbounded-unaligned.hpp:190-200 (nq=2: cos,sin; axis from `axis`) */
+  BRBD_JOINT_REVOLUTE_UNBOUNDED_UNALIGNED = 13,
+  BRBD_JOINT_TYPE_COUNT = 14
 };
 
 /* ---- matrix layout at the boundary ------------------------------------- */

@@ -309,8 +309,8 @@ static int spd_inverse(int n, const double* A, double* Ainv) {
 }
 
 /* ------------------------------------------------------------------ joints */
-static const int JOINT_NQ[BRBD_JOINT_TYPE_COUNT] = {1, 1, 1, 1, 1, 1, 7, 4, 1, 1, 2, 2, 2};
-static const int JOINT_NV[BRBD_JOINT_TYPE_COUNT] = {1, 1, 1, 1, 1, 1, 6, 3, 1, 1, 1, 1, 1};
+static const int JOINT_NQ[BRBD_JOINT_TYPE_COUNT] = {1, 1, 1, 1, 1, 1, 7, 4, 1, 1, 2, 2, 2, 2};
+static const int JOINT_NV[BRBD_JOINT_TYPE_COUNT] = {1, 1, 1, 1, 1, 1, 6, 3, 1, 1, 1, 1, 1, 1};
 
 /* Eigen Quaternion::toRotationMatrix (third-party, standard form, no
  * normalisation; used at joint-free-flyer.hpp:338-339, joint-spherical.hpp:528-529) */
@@ -424,11 +424,18 @@ static int joint_calc(int jt, const se3_t* P, const double* ax, const double* q,
         for (int k = 0; k < 3; ++k) jd->vJ[3 + k] = vj[k];
       return 0;
     }
-    case BRBD_JOINT_REVOLUTE_UNALIGNED: {
+    case BRBD_JOINT_REVOLUTE_UNALIGNED:
+    case BRBD_JOINT_REVOLUTE_UNBOUNDED_UNALIGNED: {
       /* joint-revolute-unaligned.hpp:667-708: R = toRotationMatrix(axis, cos, sin)
-       * (math/rotation.hpp, Rodrigues) */
+       * (math/rotation.hpp, Rodrigues); joint-revolute-unbounded-unaligned.hpp:190-200: the same
+       * with q = (cos, sin) */
       double s, c;
-      sincos(q[0], &s, &c);
+      if (jt == BRBD_JOINT_REVOLUTE_UNALIGNED) {
+        sincos(q[0], &s, &c);
+      } else {
+        c = q[0];
+        s = q[1];
+      }
       se3_t M;
       const double x = ax[0], y = ax[1], z = ax[2], c1 = 1 - c;
       double sx = s * x, sy = s * y, sz = s * z;

@@ -16,7 +16,7 @@ import numpy as np
 
 LD = np.longdouble
 
-RX, RY, RZ, PX, PY, PZ, FF, SPH, RU, PU, RUBX, RUBY, RUBZ = range(13)
+RX, RY, RZ, PX, PY, PZ, FF, SPH, RU, PU, RUBX, RUBY, RUBZ, RUBU = range(14)
 
 
 def skew(v):
@@ -65,6 +65,10 @@ def joint(jt, axis, q, vj):
         a = np.array(axis, dtype=LD)
         S = np.concatenate([a, Z]).reshape(6, 1)
         return axis_R(a, np.cos(LD(q[0])), np.sin(LD(q[0]))), Z, S
+    if jt == RUBU:
+        a = np.array(axis, dtype=LD)
+        S = np.concatenate([a, Z]).reshape(6, 1)
+        return axis_R(a, LD(q[0]), LD(q[1])), Z, S
     if jt == PU:
         a = np.array(axis, dtype=LD)
         S = np.concatenate([Z, a]).reshape(6, 1)
@@ -264,7 +268,7 @@ def integrate(T: Tables, q, dv):
             out[iq + 3: iq + 7] = quat_mul_exp(q[iq + 3: iq + 7], dv[iv + 3: iv + 6])
         elif jt == SPH:
             out[iq: iq + 4] = quat_mul_exp(q[iq: iq + 4], dv[iv: iv + 3])
-        elif jt in (RUBX, RUBY, RUBZ):
+        elif jt in (RUBX, RUBY, RUBZ, RUBU):
             c, s = q[iq], q[iq + 1]
             dc, ds = np.cos(dv[iv]), np.sin(dv[iv])
             out[iq], out[iq + 1] = c * dc - s * ds, s * dc + c * ds

@@ -170,9 +170,12 @@ def joint_transform(e: Emitter, mv: ModelView, i: int, sc=None):
         k = jt - M.JOINT_PX
         q = e.inp("Q", mv.idx_q[i])
         return P, [e.fma(q, P[r][k], pt[r]) for r in range(3)], None
-    if jt == M.JOINT_REVOLUTE_UNALIGNED:
+    if jt in (M.JOINT_REVOLUTE_UNALIGNED, M.JOINT_REVOLUTE_UNBOUNDED_UNALIGNED):
         if sc is None:
-            sc = e.sincos(e.inp("Q", mv.idx_q[i]))
+            if jt == M.JOINT_REVOLUTE_UNALIGNED:
+                sc = e.sincos(e.inp("Q", mv.idx_q[i]))
+            else:  # joint-revolute-unbounded-unaligned.hpp:190-200: q = (cos, sin)
+                sc = (e.inp("Q", mv.idx_q[i] + 1), e.inp("Q", mv.idx_q[i]))
         ax = [mv.c(e, i, "axis", k) for k in range(3)]
         return A.rot_mul(e, P, axis_rotation(e, ax, sc[0], sc[1])), pt, sc
     if jt == M.JOINT_PRISMATIC_UNALIGNED:
@@ -204,7 +207,7 @@ def subspace(e: Emitter, mv: ModelView, i: int) -> List[List[V]]:
         return [unit(3 + jt - M.JOINT_RUBX)]
     if jt in PRI:
         return [unit(jt - M.JOINT_PX)]
-    if jt == M.JOINT_REVOLUTE_UNALIGNED:
+    if jt in (M.JOINT_REVOLUTE_UNALIGNED, M.JOINT_REVOLUTE_UNBOUNDED_UNALIGNED):
         return [[ZERO] * 3 + [mv.c(e, i, "axis", k) for k in range(3)]]
     if jt == M.JOINT_PRISMATIC_UNALIGNED:
         return [[mv.c(e, i, "axis", k) for k in range(3)] + [ZERO] * 3]

@@ -19,8 +19,8 @@
 
 namespace brbd {
 
-static const int kJointNq[BRBD_JOINT_TYPE_COUNT] = {1, 1, 1, 1, 1, 1, 7, 4, 1, 1, 2, 2, 2};
-static const int kJointNv[BRBD_JOINT_TYPE_COUNT] = {1, 1, 1, 1, 1, 1, 6, 3, 1, 1, 1, 1, 1};
+static const int kJointNq[BRBD_JOINT_TYPE_COUNT] = {1, 1, 1, 1, 1, 1, 7, 4, 1, 1, 2, 2, 2, 2};
+static const int kJointNv[BRBD_JOINT_TYPE_COUNT] = {1, 1, 1, 1, 1, 1, 6, 3, 1, 1, 1, 1, 1, 1};
 
 struct FlatModel {
   int njoints = 0, nq = 0, nv = 0;
@@ -41,7 +41,8 @@ struct FlatModel {
   int ws_fkjac() const { return maxbranch * 12; }
 };
 
-// Unaligned joints (joint-revolute-unaligned.hpp:667-708, joint-prismatic-unaligned.hpp) run on the
+// Unaligned joints (joint-revolute-unaligned.hpp:667-708, joint-prismatic-unaligned.hpp,
+// joint-revolute-unbounded-unaligned.hpp:190-200) run on the
 // kernels of the aligned ones.  With Q a rotation that takes e_z to the axis u, the joint transform
 // is M(q) = Q M_z(q) Q^T (rotation about / translation along z), so the joint is an RZ / PZ joint
 // whose frame is the described one times Q: placement' = placement Q, the body inertia and the
@@ -76,7 +77,8 @@ inline std::string flatten(const brbd_model_desc* d, FlatModel* out, int* status
     if (p < 0 || p >= i)
       return "parents[" + std::to_string(i) + "] must satisfy 0 <= parent < joint index";
     if (jt < 0 || jt >= BRBD_JOINT_TYPE_COUNT) return "jtype[" + std::to_string(i) + "] is not a brbd_joint_type";
-    if ((jt == BRBD_JOINT_REVOLUTE_UNALIGNED || jt == BRBD_JOINT_PRISMATIC_UNALIGNED) && !d->axis)
+    if ((jt == BRBD_JOINT_REVOLUTE_UNALIGNED || jt == BRBD_JOINT_PRISMATIC_UNALIGNED ||
+         jt == BRBD_JOINT_REVOLUTE_UNBOUNDED_UNALIGNED) && !d->axis)
       return "joint " + std::to_string(i) + " is unaligned but the description has no axis table";
     const int nqj = kJointNq[jt], nvj = kJointNv[jt];
     if (d->idx_q[i] < 0 || d->idx_q[i] + nqj > d->nq) return "idx_q[" + std::to_string(i) + "] out of range";
@@ -110,7 +112,7 @@ inline std::string flatten(const brbd_model_desc* d, FlatModel* out, int* status
     jc.comp = 0;
     if (jt <= BRBD_JOINT_RZ) jc.comp = 3 + jt;
     else if (jt <= BRBD_JOINT_PZ) jc.comp = jt - BRBD_JOINT_PX;
-    else if (jt >= BRBD_JOINT_RUBX) jc.comp = 3 + (jt - BRBD_JOINT_RUBX);
+    else if (jt >= BRBD_JOINT_RUBX && jt <= BRBD_JOINT_RUBZ) jc.comp = 3 + (jt - BRBD_JOINT_RUBX);
     jc.hand_off = hand;
     hand += hand_size(nvj);
   }
@@ -238,7 +240,8 @@ inline std::string canonicalise_unaligned(FlatModel& M, const std::vector<std::v
   for (int i = 1; i < M.njoints; ++i) {
     JointConst& jc = M.tab[i];
     const bool ru = jc.jtype == BRBD_JOINT_REVOLUTE_UNALIGNED, pu = jc.jtype == BRBD_JOINT_PRISMATIC_UNALIGNED;
-    if (!ru && !pu) continue;
+    const bool rubu = jc.jtype == BRBD_JOINT_REVOLUTE_UNBOUNDED_UNALIGNED;  // -> RUBZ: q = (cos, sin) as is
+    if (!ru && !pu && !rubu) continue;
     double u[3] = {jc.axis[0], jc.axis[1], jc.axis[2]};
     const double nrm = std::sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
     if (!(nrm > 0.0)) return "joint " + std::to_string(i) + ": unaligned joint with a zero axis";
@@ -267,8 +270,8 @@ inline std::string canonicalise_unaligned(FlatModel& M, const std::vector<std::v
     jc.I[0] = I3[0]; jc.I[1] = 0.5 * (I3[1] + I3[3]); jc.I[2] = I3[4];
     jc.I[3] = 0.5 * (I3[2] + I3[6]); jc.I[4] = 0.5 * (I3[5] + I3[7]); jc.I[5] = I3[8];
     for (int k = 0; k < 9; ++k) jc.post[k] = Qt[k];
-    jc.jtype = ru ? BRBD_JOINT_RZ : BRBD_JOINT_PZ;
-    jc.comp = ru ? 5 : 2;
+    jc.jtype = ru ? BRBD_JOINT_RZ : (rubu ? BRBD_JOINT_RUBZ : BRBD_JOINT_PZ);
+    jc.comp = pu ? 2 : 5;
     for (int ch : children[i]) {  // placement_child' = Q^T . placement_child
       JointConst& cc = M.tab[ch];
       mul(Qt, cc.R, cc.R);

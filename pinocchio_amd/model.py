@@ -27,9 +27,10 @@ JOINT_SPHERICAL = 7
 JOINT_REVOLUTE_UNALIGNED = 8
 JOINT_PRISMATIC_UNALIGNED = 9
 JOINT_RUBX, JOINT_RUBY, JOINT_RUBZ = 10, 11, 12
+JOINT_REVOLUTE_UNBOUNDED_UNALIGNED = 13
 
-JOINT_NQ = (1, 1, 1, 1, 1, 1, 7, 4, 1, 1, 2, 2, 2)
-JOINT_NV = (1, 1, 1, 1, 1, 1, 6, 3, 1, 1, 1, 1, 1)
+JOINT_NQ = (1, 1, 1, 1, 1, 1, 7, 4, 1, 1, 2, 2, 2, 2)
+JOINT_NV = (1, 1, 1, 1, 1, 1, 6, 3, 1, 1, 1, 1, 1, 1)
 
 # pinocchio shortname() of each kind (e.g. joint-revolute.hpp:848-851)
 JOINT_SHORTNAMES = (
@@ -38,6 +39,7 @@ JOINT_SHORTNAMES = (
     "JointModelFreeFlyer", "JointModelSpherical",
     "JointModelRevoluteUnaligned", "JointModelPrismaticUnaligned",
     "JointModelRUBX", "JointModelRUBY", "JointModelRUBZ",
+    "JointModelRevoluteUnboundedUnaligned",
 )
 SHORTNAME_TO_TYPE = {n: i for i, n in enumerate(JOINT_SHORTNAMES)}
 
@@ -151,7 +153,7 @@ class Model:
         self.jointPlacements.append(placement.copy())
         self.inertias.append(Inertia.Zero())
         ax = np.zeros(3) if axis is None else np.asarray(axis, dtype=np.float64).reshape(3)
-        if jtype in (JOINT_REVOLUTE_UNALIGNED, JOINT_PRISMATIC_UNALIGNED):
+        if jtype in (JOINT_REVOLUTE_UNALIGNED, JOINT_PRISMATIC_UNALIGNED, JOINT_REVOLUTE_UNBOUNDED_UNALIGNED):
             n = np.linalg.norm(ax)
             if not n > 0:
                 raise ValueError("unaligned joint needs a non-zero axis")
@@ -272,7 +274,7 @@ class Model:
                 q[iq + 6] = 1.0
             elif jt == JOINT_SPHERICAL:
                 q[iq + 3] = 1.0
-            elif jt in (JOINT_RUBX, JOINT_RUBY, JOINT_RUBZ):
+            elif jt in (JOINT_RUBX, JOINT_RUBY, JOINT_RUBZ, JOINT_REVOLUTE_UNBOUNDED_UNALIGNED):
                 q[iq] = 1.0
         return q
 
@@ -291,7 +293,7 @@ class Model:
             elif jt == JOINT_SPHERICAL:
                 quat = rng.standard_normal((4, B))
                 q[iq:iq + 4] = quat / np.linalg.norm(quat, axis=0)
-            elif jt in (JOINT_RUBX, JOINT_RUBY, JOINT_RUBZ):
+            elif jt in (JOINT_RUBX, JOINT_RUBY, JOINT_RUBZ, JOINT_REVOLUTE_UNBOUNDED_UNALIGNED):
                 th = rng.uniform(-np.pi, np.pi, B)
                 q[iq] = np.cos(th)
                 q[iq + 1] = np.sin(th)

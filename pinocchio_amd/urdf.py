@@ -13,7 +13,7 @@ Honours the rules of pinocchio's URDF parser that decide the constant tables
   gives a valid model, only the dof numbering changes);
 * REVOLUTE with axis exactly +X/+Y/+Z -> RX/RY/RZ, anything else ->
   RevoluteUnaligned(axis.normalized()) (``model.hxx:493-527,619-626``);
-  CONTINUOUS -> RUBX/RUBY/RUBZ (``src/parsers/urdf/model.cpp:164-192``);
+  CONTINUOUS -> RUBX/RUBY/RUBZ, RevoluteUnboundedUnaligned otherwise (``src/parsers/urdf/model.cpp:164-192``);
   PRISMATIC likewise; FIXED -> no joint, the child's inertia is merged into the
   parent joint's body through the frame placement (``model.hxx:331-346``);
 * URDF inertial -> Inertia(mass, com, R I R^T) (``src/parsers/urdf/model.cpp:30-42``).
@@ -116,9 +116,7 @@ def build_model_from_urdf(text: str, free_flyer: bool = True, name: Optional[str
             if jt == "revolute":
                 jtype = M.JOINT_RX + k if k is not None else M.JOINT_REVOLUTE_UNALIGNED
             elif jt == "continuous":
-                if k is None:
-                    raise ValueError(f"joint {jn}: RevoluteUnboundedUnaligned is not supported")
-                jtype = M.JOINT_RUBX + k
+                jtype = M.JOINT_RUBX + k if k is not None else M.JOINT_REVOLUTE_UNBOUNDED_UNALIGNED
             elif jt == "prismatic":
                 jtype = M.JOINT_PX + k if k is not None else M.JOINT_PRISMATIC_UNALIGNED
             elif jt == "floating":

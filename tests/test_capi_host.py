@@ -74,12 +74,12 @@ def test_canonical_form_of_unaligned_joints_is_the_same_robot():
     import oracle
     from util import inputs
     kinds = [M.JOINT_RX, M.JOINT_PY, M.JOINT_REVOLUTE_UNALIGNED, M.JOINT_PRISMATIC_UNALIGNED, M.JOINT_SPHERICAL,
-             M.JOINT_REVOLUTE_UNALIGNED, M.JOINT_RUBZ]
+             M.JOINT_REVOLUTE_UNALIGNED, M.JOINT_RUBZ, M.JOINT_REVOLUTE_UNBOUNDED_UNALIGNED]
     for seed in range(4):
         m = S.random_tree(500 + seed, 10, kinds=kinds, root_kind=M.JOINT_FREEFLYER if seed % 2 else None)
-        assert any(t in (M.JOINT_REVOLUTE_UNALIGNED, M.JOINT_PRISMATIC_UNALIGNED) for t in m.jtypes[1:])
+        assert any(t in (M.JOINT_REVOLUTE_UNALIGNED, M.JOINT_PRISMATIC_UNALIGNED, M.JOINT_REVOLUTE_UNBOUNDED_UNALIGNED) for t in m.jtypes[1:])
         mc, post = capi.canonical_form(m)
-        assert not any(t in (M.JOINT_REVOLUTE_UNALIGNED, M.JOINT_PRISMATIC_UNALIGNED) for t in mc.jtypes[1:])
+        assert not any(t in (M.JOINT_REVOLUTE_UNALIGNED, M.JOINT_PRISMATIC_UNALIGNED, M.JOINT_REVOLUTE_UNBOUNDED_UNALIGNED) for t in mc.jtypes[1:])
         O, Oc = oracle.Oracle(m), oracle.Oracle(mc)
         q, v, a = inputs(m, 6, seed)
         tau = O.rnea(q, v, a)

@@ -13,6 +13,7 @@ from util import inputs, rel_err_cols
 
 KINDS_ALL = [M.JOINT_RX, M.JOINT_RY, M.JOINT_RZ, M.JOINT_PX, M.JOINT_PY, M.JOINT_PZ, M.JOINT_SPHERICAL,
              M.JOINT_RUBX, M.JOINT_RUBY, M.JOINT_RUBZ, M.JOINT_FREEFLYER, M.JOINT_REVOLUTE_UNALIGNED,
+             M.JOINT_REVOLUTE_UNBOUNDED_UNALIGNED,
              M.JOINT_PRISMATIC_UNALIGNED]
 
 

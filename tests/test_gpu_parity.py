@@ -376,9 +376,9 @@ def test_unaligned_joints(seed):
     canonicalises them onto the RZ / PZ code of the table-driven kernels; every algorithm, both
     boundary layouts, against the oracle, which evaluates them natively."""
     kinds = [M.JOINT_RX, M.JOINT_PY, M.JOINT_REVOLUTE_UNALIGNED, M.JOINT_PRISMATIC_UNALIGNED, M.JOINT_SPHERICAL,
-             M.JOINT_REVOLUTE_UNALIGNED, M.JOINT_RUBZ]
+             M.JOINT_REVOLUTE_UNALIGNED, M.JOINT_RUBZ, M.JOINT_REVOLUTE_UNBOUNDED_UNALIGNED]
     model = S.random_tree(500 + seed, 10, kinds=kinds, root_kind=M.JOINT_FREEFLYER if seed % 2 else None)
-    assert any(t in (M.JOINT_REVOLUTE_UNALIGNED, M.JOINT_PRISMATIC_UNALIGNED) for t in model.jtypes[1:])
+    assert any(t in (M.JOINT_REVOLUTE_UNALIGNED, M.JOINT_PRISMATIC_UNALIGNED, M.JOINT_REVOLUTE_UNBOUNDED_UNALIGNED) for t in model.jtypes[1:])
     pool = parallel.ModelPool(model, 1)
     assert pool.device_model(0).compiled_kernels() == ""
     _check_all(pool, model, oracle.Oracle(model))

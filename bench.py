@@ -30,8 +30,8 @@ FP64_PEAK_TFLOPS = 78.6    # MI355X vector FP64 (spec; no MFMA on this path)
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=200)
-    p.add_argument("--warmup", type=int, default=20)
+    p.add_argument("--steps", type=int, default=2000)
+    p.add_argument("--warmup", type=int, default=300)
     p.add_argument("--batch", type=int, default=65536, help="instances per GPU")
     p.add_argument("--model", default="simple_humanoid")
     p.add_argument("--no-cpu-baseline", action="store_true")

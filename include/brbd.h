@@ -148,6 +148,20 @@ int brbd_aba(brbd_model* m, int64_t B, const double* q, int64_t ldq, const doubl
              const double* tau, int64_t ldtau, double* ddq, int64_t ldddq, int layout, int memspace,
              void* stream);
 
+/* rnea / aba with external forces: rnea(model, data, q, v, a, fext) (algorithm/rnea.hxx:171-219,
+ * f[i] -= fext[i]) and aba(model, data, q, v, tau, fext) in the WORLD convention
+ * (algorithm/aba.hxx:296-354, of[i] -= oMi[i].act(fext[i])).  fext is a (6 * njoints) x B matrix
+ * in the layout of the call: rows 6i .. 6i+5 = the spatial force [linear; angular] on joint i in
+ * that joint's frame (the reference's aligned_vector<Force> of model.joints.size() entries, the
+ * universe's entry included and ignored).  The parallel wrappers of the reference have no such
+ * overload; these two are what a batched caller with contact forces binds instead. */
+int brbd_rnea_fext(brbd_model* m, int64_t B, const double* q, int64_t ldq, const double* v, int64_t ldv,
+                   const double* a, int64_t lda, const double* fext, int64_t ldfext, double* tau,
+                   int64_t ldtau, int layout, int memspace, void* stream);
+int brbd_aba_fext(brbd_model* m, int64_t B, const double* q, int64_t ldq, const double* v, int64_t ldv,
+                  const double* tau, int64_t ldtau, const double* fext, int64_t ldfext, double* ddq,
+                  int64_t ldddq, int layout, int memspace, void* stream);
+
 /* forwardKinematics(q) + computeJointJacobians(q) for B instances
  * (algorithm/kinematics.hxx:52-97, algorithm/jacobian.hxx:38-95).
  * J: per instance 6 x nv column-major (row 0-2 linear, 3-5 angular), WORLD

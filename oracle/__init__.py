@@ -38,6 +38,8 @@ def lib():
         L.brbd_oracle_rnea.argtypes = [vp, dp, dp, dp, dp]
         L.brbd_oracle_aba_world.argtypes = [vp, dp, dp, dp, dp]
         L.brbd_oracle_aba_local.argtypes = [vp, dp, dp, dp, dp]
+        L.brbd_oracle_rnea_fext.argtypes = [vp, dp, dp, dp, dp, dp]
+        L.brbd_oracle_aba_fext.argtypes = [vp, dp, dp, dp, dp, ctypes.c_int, dp]
         L.brbd_oracle_fk_jacobians.argtypes = [vp, dp, dp, dp]
         L.brbd_oracle_rnea_derivatives.argtypes = [vp, dp, dp, dp, dp, dp, dp, dp]
         i64 = ctypes.c_int64
@@ -94,6 +96,28 @@ class Oracle:
                 rc = lib().brbd_oracle_aba_local(self._ref, _p(qb), _p(vb), _p(tb), _p(out))
                 assert rc == 0, rc
                 ddq[:, b] = out
+        return ddq
+
+    def rnea_fext(self, q, v, a, fext):
+        """rnea(model, data, q, v, a, fext) per column; fext (6*njoints, B), joint frame."""
+        q, v, a, f = _cols(q, self.nq), _cols(v, self.nv), _cols(a, self.nv), _cols(fext, 6 * self.njoints)
+        tau = np.zeros((self.nv, q.shape[1]), order="F")
+        for b in range(q.shape[1]):
+            cols = [np.ascontiguousarray(x[:, b]) for x in (q, v, a, f)]
+            out = np.zeros(self.nv)
+            assert lib().brbd_oracle_rnea_fext(self._ref, *[_p(c) for c in cols], _p(out)) == 0
+            tau[:, b] = out
+        return tau
+
+    def aba_fext(self, q, v, tau, fext, convention="world"):
+        q, v, tau, f = _cols(q, self.nq), _cols(v, self.nv), _cols(tau, self.nv), _cols(fext, 6 * self.njoints)
+        ddq = np.zeros((self.nv, q.shape[1]), order="F")
+        for b in range(q.shape[1]):
+            cols = [np.ascontiguousarray(x[:, b]) for x in (q, v, tau, f)]
+            out = np.zeros(self.nv)
+            rc = lib().brbd_oracle_aba_fext(self._ref, *[_p(c) for c in cols], 0 if convention == "world" else 1, _p(out))
+            assert rc == 0, rc
+            ddq[:, b] = out
         return ddq
 
     def fk_jacobians(self, q, threads=1):

@@ -608,8 +608,10 @@ static void ws_free(ws_t* w) {
 
 /* ================================================================== RNEA */
 /* algorithm/rnea.hxx:117-161; forward step :45-79, backward step :92-107 */
+/* fext (may be NULL): 6 doubles [lin; ang] per joint, joint 0 included and ignored, expressed in
+ * the joint frame: rnea.hxx:171-219 (data.f[i] -= fext[i], :205) */
 static void rnea_ws(const brbd_model_desc* m, ws_t* w, const double* q, const double* v,
-                    const double* a, double* tau) {
+                    const double* a, const double* fext, double* tau) {
   const int n = m->njoints;
   for (int k = 0; k < m->nv; ++k) tau[k] = 0.0; /* :136 */
   for (int k = 0; k < 6; ++k) w->v[k] = 0.0;     /* :137 */
@@ -642,6 +644,8 @@ static void rnea_ws(const brbd_model_desc* m, ws_t* w, const double* q, const do
     inertia_mul(&Y, ai, w->f + 6 * i); /* :74 */
     force_cross(vi, w->h + 6 * i, tmp); /* :75 */
     for (int k = 0; k < 6; ++k) w->f[6 * i + k] += tmp[k];
+    if (fext)
+      for (int k = 0; k < 6; ++k) w->f[6 * i + k] -= fext[6 * i + k]; /* :205 */
   }
   for (int i = n - 1; i > 0; --i) {
     const int p = m->parents[i];
@@ -659,8 +663,9 @@ static void rnea_ws(const brbd_model_desc* m, ws_t* w, const double* q, const do
 
 /* ================================================================== ABA (WORLD) */
 /* algorithm/aba.hxx:243-294; pass1 :102-139, pass2 :153-193, pass3 :207-232 */
+/* fext as for rnea_ws: aba.hxx:296-354 (data.of[i] -= data.oMi[i].act(fext[i]), :338) */
 static int aba_world_ws(const brbd_model_desc* m, ws_t* w, const double* q, const double* v,
-                        const double* tau, double* ddq) {
+                        const double* tau, const double* fext, double* ddq) {
   const int n = m->njoints;
   double* ov = w->v;
   double* oa_gf = w->a;
@@ -700,6 +705,11 @@ static int aba_world_ws(const brbd_model_desc* m, ws_t* w, const double* q, cons
     inertia_matrix(&w->Ycrb[i], w->Yaba + 36 * i);     /* :135 */
     inertia_mul(&w->Ycrb[i], ovi, w->h + 6 * i);       /* :137 */
     force_cross(ovi, w->h + 6 * i, of + 6 * i);        /* :138 */
+    if (fext) {                                         /* :338 */
+      double tmp[6];
+      se3_act_force(&w->oMi[i], fext + 6 * i, tmp);
+      for (int k = 0; k < 6; ++k) of[6 * i + k] -= tmp[k];
+    }
   }
 
   for (int i = n - 1; i > 0; --i) { /* pass 2 */
@@ -766,8 +776,9 @@ static int aba_world_ws(const brbd_model_desc* m, ws_t* w, const double* q, cons
 /* ================================================================== ABA (LOCAL) */
 /* algorithm/aba.hxx:488-542; pass1 :378-403, pass2 :417-443, pass3 :457-477;
  * calc_aba e.g. joint-revolute.hpp:832-846; SE3actOn aba.hxx:25-76 */
+/* fext as for rnea_ws: aba.hxx:544-603 (data.f[i] -= fext[i], :587) */
 static int aba_local_ws(const brbd_model_desc* m, ws_t* w, const double* q, const double* v,
-                        const double* tau, double* ddq) {
+                        const double* tau, const double* fext, double* ddq) {
   const int n = m->njoints;
   for (int k = 0; k < 6; ++k) w->v[k] = 0.0;
   for (int k = 0; k < 3; ++k) {
@@ -795,6 +806,8 @@ static int aba_local_ws(const brbd_model_desc* m, ws_t* w, const double* q, cons
     inertia_matrix(&Y, w->Yaba + 36 * i);   /* :400 */
     inertia_mul(&Y, vi, w->h + 6 * i);      /* :401 */
     force_cross(vi, w->h + 6 * i, w->f + 6 * i);
+    if (fext)
+      for (int k = 0; k < 6; ++k) w->f[6 * i + k] -= fext[6 * i + k]; /* :587 */
   }
   for (int i = n - 1; i > 0; --i) {
     const int p = m->parents[i];
@@ -1097,7 +1110,7 @@ int brbd_oracle_rnea(const brbd_model_desc* m, const double* q, const double* v,
                      double* tau) {
   if (check_model(m)) return -1;
   ws_t* w = ws_alloc(m);
-  rnea_ws(m, w, q, v, a, tau);
+  rnea_ws(m, w, q, v, a, NULL, tau);
   ws_free(w);
   return 0;
 }
@@ -1105,7 +1118,7 @@ int brbd_oracle_aba_world(const brbd_model_desc* m, const double* q, const doubl
                           const double* tau, double* ddq) {
   if (check_model(m)) return -1;
   ws_t* w = ws_alloc(m);
-  int rc = aba_world_ws(m, w, q, v, tau, ddq);
+  int rc = aba_world_ws(m, w, q, v, tau, NULL, ddq);
   ws_free(w);
   return rc;
 }
@@ -1113,7 +1126,24 @@ int brbd_oracle_aba_local(const brbd_model_desc* m, const double* q, const doubl
                           const double* tau, double* ddq) {
   if (check_model(m)) return -1;
   ws_t* w = ws_alloc(m);
-  int rc = aba_local_ws(m, w, q, v, tau, ddq);
+  int rc = aba_local_ws(m, w, q, v, tau, NULL, ddq);
+  ws_free(w);
+  return rc;
+}
+/* with external forces, one instance (convention: 0 = WORLD, 1 = LOCAL) */
+int brbd_oracle_rnea_fext(const brbd_model_desc* m, const double* q, const double* v, const double* a,
+                          const double* fext, double* tau) {
+  if (check_model(m)) return -1;
+  ws_t* w = ws_alloc(m);
+  rnea_ws(m, w, q, v, a, fext, tau);
+  ws_free(w);
+  return 0;
+}
+int brbd_oracle_aba_fext(const brbd_model_desc* m, const double* q, const double* v, const double* tau,
+                         const double* fext, int convention, double* ddq) {
+  if (check_model(m)) return -1;
+  ws_t* w = ws_alloc(m);
+  int rc = convention ? aba_local_ws(m, w, q, v, tau, fext, ddq) : aba_world_ws(m, w, q, v, tau, fext, ddq);
   ws_free(w);
   return rc;
 }
@@ -1174,7 +1204,7 @@ int brbd_oracle_rnea_batch(const brbd_model_desc* m, int64_t B, const double* q,
 #else
     const int tid = 0;
 #endif
-    rnea_ws(m, pool[tid], q + i * m->nq, v + i * m->nv, a + i * m->nv, tau + i * m->nv);
+    rnea_ws(m, pool[tid], q + i * m->nq, v + i * m->nv, a + i * m->nv, NULL, tau + i * m->nv);
   }
   for (int t = 0; t < nt; ++t) ws_free(pool[t]);
   free(pool);
@@ -1200,7 +1230,7 @@ int brbd_oracle_aba_batch(const brbd_model_desc* m, int64_t B, const double* q, 
 #else
     const int tid = 0;
 #endif
-    if (aba_world_ws(m, pool[tid], q + i * m->nq, v + i * m->nv, tau + i * m->nv, ddq + i * m->nv)) {
+    if (aba_world_ws(m, pool[tid], q + i * m->nq, v + i * m->nv, tau + i * m->nv, NULL, ddq + i * m->nv)) {
 #pragma omp atomic write
       bad = 1;
     }

@@ -37,6 +37,12 @@ int brbd_oracle_aba_local(const brbd_model_desc* m, const double* q, const doubl
 /* algorithm/kinematics.hxx:52-97 + algorithm/jacobian.hxx:38-95.
  * J: 6 x nv column-major (may be NULL); oMi: njoints x 12, rotation column-major
  * then translation (may be NULL). */
+/* rnea / aba with external forces (rnea.hxx:171-219, aba.hxx:296-354 WORLD, :544-603 LOCAL):
+ * fext = 6 doubles [lin; ang] per joint (joint 0 included, ignored), in the joint frame */
+int brbd_oracle_rnea_fext(const brbd_model_desc* m, const double* q, const double* v, const double* a,
+                          const double* fext, double* tau);
+int brbd_oracle_aba_fext(const brbd_model_desc* m, const double* q, const double* v, const double* tau,
+                         const double* fext, int convention, double* ddq);
 int brbd_oracle_fk_jacobians(const brbd_model_desc* m, const double* q, double* J, double* oMi);
 /* algorithm/rnea-derivatives.hxx:472-541.  Outputs nv x nv column-major, fully
  * written (zeros included); dtau_da upper triangle only.  dtau_da / tau may be NULL. */

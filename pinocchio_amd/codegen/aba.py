@@ -145,6 +145,8 @@ def generate(mv: J.ModelView, e: Emitter) -> Emitter:
         cw, Iw = A.inertia_to_world(e, R, t, c, I)
         Ia = A.inertia_to_sym6(e, m, cw, Iw)
         of = A.force_cross(e, ov, A.inertia_mul(e, m, cw, Iw, ov))
+        # aba.hxx:338 (kernel variants with external forces): of[i] -= oMi.act(fext[i])
+        of = e.cond_sub(of, lambda: A.act_force(e, R, t, [e.inp("F", 6 * i + k) for k in range(6)]))
         return Ia, of
 
     def backward_root(i, R, t, Jc, Ia, of):

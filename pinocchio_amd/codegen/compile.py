@@ -54,7 +54,7 @@ FINE = set(os.environ.get("BRBD_CG_FINE", "deriv").split(","))
 # scratch beyond ~200 doubles (512 registers per lane at one wave per SIMD, minus addressing).
 LADDER = {"deriv": [(64, 80, 32, 64), (40, 80, 32, 64), (24, 80, 16, 64), (8, 80, 0, 64), (0, 80, 0, 64),
                     (0, 80, 0, 48), (0, 80, 0, 24)]}
-LIVE_MAX = {"deriv": 190}
+LIVE_MAX = {"deriv": 182}
 
 _IDENT = re.compile(r"\b([a-z][a-z]?_?[0-9]+(?:_[0-9]+)?|[sc]_t[0-9]+)\b")
 
@@ -124,6 +124,10 @@ _CPU_SHELL = r"""
 #define IN_Q(k) q[k]
 #define IN_V(k) v[k]
 #define IN_X(k) x[k]
+#define IN_F(k) fx[k]
+#ifndef WANT
+#define WANT 0
+#endif
 #define OUT(k, val) out[k] = (val)
 #define OUT2(k, val) out2[k] = (val)
 #define OUT3(k, val) out3[k] = (val)
@@ -147,17 +151,17 @@ _CPU_SHELL = r"""
 #define PK_GLB_LD2(p, a, b) do { a = glb[2 * (p)]; b = glb[2 * (p) + 1]; } while (0)
 #define VISIT_END() do { } while (0)
 #define OPAQUE(x) do { } while (0)
-static void one(const double* ct, const double* q, const double* v, const double* x, double* out,
-                double* out2, double* out3, double* out4, double* lds, double* glb) {
-  (void)ct; (void)q; (void)v; (void)x; (void)out; (void)out2; (void)out3; (void)out4; (void)lds; (void)glb;
+static void one(const double* ct, const double* q, const double* v, const double* x, const double* fx,
+                double* out, double* out2, double* out3, double* out4, double* lds, double* glb) {
+  (void)ct; (void)q; (void)v; (void)x; (void)fx; (void)out; (void)out2; (void)out3; (void)out4; (void)lds; (void)glb;
 #include "BODY"
 }
 void spec_batch(const double* ct, long B, const double* q, long ldq, const double* v, long ldv,
                 const double* x, long ldx, double* out, long ldo, double* out2, long ldo2, double* out3,
-                long ldo3, double* out4, long ldo4) {
+                long ldo3, double* out4, long ldo4, const double* fx, long ldf) {
   double lds[LDS_N + 2], glb[GLB_N + 2];
   for (long b = 0; b < B; ++b)
-    one(ct, q + b * ldq, v ? v + b * ldv : 0, x ? x + b * ldx : 0, out + b * ldo, out2 ? out2 + b * ldo2 : 0,
+    one(ct, q + b * ldq, v ? v + b * ldv : 0, x ? x + b * ldx : 0, fx ? fx + b * ldf : 0, out + b * ldo, out2 ? out2 + b * ldo2 : 0,
         out3 ? out3 + b * ldo3 : 0, out4 ? out4 + b * ldo4 : 0, lds, glb);
 }
 """
@@ -166,7 +170,7 @@ void spec_batch(const double* ct, long B, const double* q, long ldq, const doubl
 class CpuKernel:
     """The generated body compiled for the host (checker of the generator, never a product path)."""
 
-    def __init__(self, mv: joints.ModelView, algo: str, skip_zeros: bool = False, **kw):
+    def __init__(self, mv: joints.ModelView, algo: str, skip_zeros: bool = False, want: int = 0, **kw):
         self.mv, self.kernel = mv, build_kernel(mv, algo, **kw)
         self.ct = pack_constants(mv, self.kernel.const_list)
         self.dir = tempfile.mkdtemp(prefix="brbd_cg_")
@@ -180,12 +184,12 @@ class CpuKernel:
         so = os.path.join(self.dir, "spec.so")
         # -ffp-contract=off: only the FMAs the generator asked for
         subprocess.check_call(["gcc", "-O1", "-ffp-contract=off", "-shared", "-fPIC", "-o", so, src, "-lm"]
-                              + (["-DSKIP_ZEROS"] if skip_zeros else []))
+                              + (["-DSKIP_ZEROS"] if skip_zeros else []) + ["-DWANT=%d" % want])
         self.lib = ctypes.CDLL(so)
         dp, l = ctypes.POINTER(ctypes.c_double), ctypes.c_long
-        self.lib.spec_batch.argtypes = [dp, l, dp, l, dp, l, dp, l, dp, l, dp, l, dp, l, dp, l]
+        self.lib.spec_batch.argtypes = [dp, l, dp, l, dp, l, dp, l, dp, l, dp, l, dp, l, dp, l, dp, l]
 
-    def run(self, q, v=None, x=None, out_rows=(0, 0, 0)):
+    def run(self, q, v=None, x=None, out_rows=(0, 0, 0), fext=None):
         out_rows = tuple(out_rows) + (0,) * (4 - len(out_rows))
         def P(a):
             return None if a is None else a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
@@ -194,10 +198,12 @@ class CpuKernel:
         B = q.shape[1]
         v = None if v is None else np.asfortranarray(v, dtype=np.float64)
         x = None if x is None else np.asfortranarray(x, dtype=np.float64)
+        fext = None if fext is None else np.asfortranarray(fext, dtype=np.float64)
         outs = [np.zeros((r, B), order="F") if r else None for r in out_rows]
         self.lib.spec_batch(P(self.ct), B, P(q), q.shape[0], P(v), 0 if v is None else v.shape[0], P(x),
                             0 if x is None else x.shape[0], P(outs[0]), out_rows[0], P(outs[1]), out_rows[1],
-                            P(outs[2]), out_rows[2], P(outs[3]), out_rows[3])
+                            P(outs[2]), out_rows[2], P(outs[3]), out_rows[3], P(fext),
+                            0 if fext is None else fext.shape[0])
         return outs
 
 

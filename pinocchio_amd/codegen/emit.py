@@ -127,6 +127,7 @@ class Emitter:
         self.const_cache: Dict[tuple, V] = {}
         self.in_cache: Dict[tuple, V] = {}
         self.stats = {"fp": 0, "ld": 0, "st": 0, "ct": 0, "trans": 0}
+        self.has_blocks = False
         self.fillers: List[str] = []  # stores that depend on nothing (structural zeros)
         self.opaque_regs = False  # experiment: made register pressure worse with hipcc 7.2
 
@@ -194,6 +195,26 @@ class Emitter:
         mac = "OUT" if which == 1 else "OUT%d" % which
         self.stmt("%s(%d, %s);" % (mac, k, x.code()))
         self.stats["st"] += 1
+
+    def cond_sub(self, vals: Sequence[V], thunk, bit: int = 32) -> List[V]:
+        """vals - thunk() in the kernel variants whose WANT mask has ``bit`` (external forces),
+        vals unchanged in the others: the statements thunk() emits sit in an ``if (WANT & bit)``
+        block, a compile-time constant in every instantiation."""
+        names = []
+        for v in vals:
+            n = self._tmp()
+            self.stmt("double %s = %s;" % (n, v.code()))
+            names.append(n)
+        saved = dict(self.cse)
+        self.stmt("if (WANT & %d) {" % bit)
+        for n, d in zip(names, thunk()):
+            if not d.is_zero():
+                self.stmt("%s -= %s;" % (n, d.code()))
+                self.stats["fp"] += 1
+        self.stmt("}")
+        self.cse = saved  # (what the block computed is out of scope after it)
+        self.has_blocks = True
+        return [V(n) for n in names]
 
     def out_filler(self, k: int, x: V, which: int = 1):
         """An output that depends on no computed value (a structural zero): text() spreads these
@@ -387,6 +408,7 @@ class Emitter:
         n = len(self.visits)
         size = [len(v.body) for v in self.visits]
         if fine:
+            assert not self.has_blocks, "statement-level placement could land inside a conditional block"
             start = [0] * (n + 1)
             for k in range(n):
                 start[k + 1] = start[k] + size[k]

@@ -57,6 +57,8 @@ def generate(mv: J.ModelView, e: Emitter) -> Emitter:
             m, c, I = mv.inertia(e, i)
             h = A.inertia_mul(e, m, c, I, v)                                      # :73
             f = A.vadd(e, A.inertia_mul(e, m, c, I, a), A.force_cross(e, v, h))  # :74-75
+            # rnea.hxx:205 (kernel variants with external forces): f[i] -= fext[i], joint frame
+            f = e.cond_sub(f, lambda: [e.inp("F", 6 * i + k) for k in range(6)])
             if leaf:
                 backward(i, f, R, t)
             else:

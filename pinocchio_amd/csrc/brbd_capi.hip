@@ -251,15 +251,15 @@ int launch_algo(brbd_model* m, int algo, KArgs& A, int layout, hipStream_t strea
   if (sk) {
     if (algo == BRBD_ALGO_FK_JAC) variant = (A.out ? 1 : 0) | (A.out2 ? 2 : 0);
     else if (algo == BRBD_ALGO_RNEA_DERIV) variant = m->prezeroed ? 1 : 0;
-    else variant = 0;
+    else variant = A.fext ? 1 : 0;  // rnea / aba: kernel variant with external forces
     // buffer ranges: every matrix must span less than 4 GiB (32-bit byte offsets)
     const int64_t nn = (int64_t)F.nv * F.nv;
     const bool der = algo == BRBD_ALGO_RNEA_DERIV;
-    const int64_t dofs[7] = {F.nq, F.nv, F.nv, der ? nn : (algo == BRBD_ALGO_FK_JAC ? 6 * (int64_t)F.nv : F.nv),
-                             der ? nn : 12 * (int64_t)F.njoints, nn, F.nv};
-    const void* ptrs[7] = {A.q, A.v, A.a, A.out, A.out2, A.out3, A.out4};
-    const int64_t lds_[7] = {A.ldq, A.ldv, A.lda, A.ldout, A.ldout2, A.ldout3, A.ldout4};
-    for (int k = 0; k < 7 && sk; ++k) {
+    const int64_t dofs[8] = {F.nq, F.nv, F.nv, der ? nn : (algo == BRBD_ALGO_FK_JAC ? 6 * (int64_t)F.nv : F.nv),
+                             der ? nn : 12 * (int64_t)F.njoints, nn, F.nv, 6 * (int64_t)F.njoints};
+    const void* ptrs[8] = {A.q, A.v, A.a, A.out, A.out2, A.out3, A.out4, A.fext};
+    const int64_t lds_[8] = {A.ldq, A.ldv, A.lda, A.ldout, A.ldout2, A.ldout3, A.ldout4, A.ldfext};
+    for (int k = 0; k < 8 && sk; ++k) {
       A.nb[k] = 0;
       if (!ptrs[k]) continue;
       const double span = 8.0 * (layout == BRBD_BATCH_MAJOR ? (double)lds_[k] * (double)dofs[k]
@@ -524,15 +524,17 @@ struct Staged {
 size_t padded(size_t doubles) { return (doubles + 31) & ~size_t(31); }
 }  // namespace
 
-int brbd_rnea(brbd_model* m, int64_t B, const double* q, int64_t ldq, const double* v, int64_t ldv,
-              const double* a, int64_t lda, double* tau, int64_t ldtau, int layout, int memspace,
-              void* stream) {
+// rnea with (fext != NULL) or without external forces
+static int rnea_impl(brbd_model* m, int64_t B, const double* q, int64_t ldq, const double* v, int64_t ldv,
+                     const double* a, int64_t lda, const double* fext, int64_t ldf, bool with_fext,
+                     double* tau, int64_t ldtau, int layout, int memspace, void* stream) {
   int rc = check_common(m, B, layout, memspace);
   if (rc) return rc;
   const FlatModel& F = m->flat;
   if ((rc = check_mat("q", q, ldq, F.nq, B, layout))) return rc;
   if ((rc = check_mat("v", v, ldv, F.nv, B, layout))) return rc;
   if ((rc = check_mat("a", a, lda, F.nv, B, layout))) return rc;
+  if (with_fext && (rc = check_mat("fext", fext, ldf, 6 * (int64_t)F.njoints, B, layout))) return rc;
   if ((rc = check_mat("tau", tau, ldtau, F.nv, B, layout))) return rc;
   if (B == 0) return BRBD_OK;
   DevGuard dg(m->device);
@@ -540,15 +542,23 @@ int brbd_rnea(brbd_model* m, int64_t B, const double* q, int64_t ldq, const doub
   hipStream_t s = (hipStream_t)stream;
   KArgs A{};
   fill_common(m, A, B);
+  A.ldfext = ldf;
   if (memspace == BRBD_DEVICE) {
     A.q = q; A.ldq = ldq; A.v = v; A.ldv = ldv; A.a = a; A.lda = lda; A.out = tau; A.ldout = ldtau;
+    A.fext = with_fext ? fext : nullptr;
     return launch_algo(m, BRBD_ALGO_RNEA, A, layout, s);
   }
   const size_t nq_ = mat_span(ldq, F.nq, B, layout), nv_ = mat_span(ldv, F.nv, B, layout),
-               na_ = mat_span(lda, F.nv, B, layout), nt_ = mat_span(ldtau, F.nv, B, layout);
-  if ((rc = ensure_stage(m, padded(nq_) + padded(nv_) + padded(na_) + padded(nt_)))) return rc;
+               na_ = mat_span(lda, F.nv, B, layout), nt_ = mat_span(ldtau, F.nv, B, layout),
+               nf_ = with_fext ? mat_span(ldf, 6 * (int64_t)F.njoints, B, layout) : 0;
+  if ((rc = ensure_stage(m, padded(nq_) + padded(nv_) + padded(na_) + padded(nt_) + padded(nf_)))) return rc;
   Staged st{m, s};
   double *dq = st.take(nq_), *dv = st.take(nv_), *da = st.take(na_), *dt = st.take(nt_);
+  if (with_fext) {
+    double* df = st.take(nf_);
+    HIP_TRY(hipMemcpyAsync(df, fext, nf_ * 8, hipMemcpyHostToDevice, s));
+    A.fext = df;
+  }
   HIP_TRY(hipMemcpyAsync(dq, q, nq_ * 8, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(dv, v, nv_ * 8, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(da, a, na_ * 8, hipMemcpyHostToDevice, s));
@@ -561,9 +571,21 @@ int brbd_rnea(brbd_model* m, int64_t B, const double* q, int64_t ldq, const doub
   return BRBD_OK;
 }
 
-int brbd_aba(brbd_model* m, int64_t B, const double* q, int64_t ldq, const double* v, int64_t ldv,
-             const double* tau, int64_t ldtau, double* ddq, int64_t ldddq, int layout, int memspace,
-             void* stream) {
+int brbd_rnea(brbd_model* m, int64_t B, const double* q, int64_t ldq, const double* v, int64_t ldv,
+              const double* a, int64_t lda, double* tau, int64_t ldtau, int layout, int memspace,
+              void* stream) {
+  return rnea_impl(m, B, q, ldq, v, ldv, a, lda, nullptr, 0, false, tau, ldtau, layout, memspace, stream);
+}
+
+int brbd_rnea_fext(brbd_model* m, int64_t B, const double* q, int64_t ldq, const double* v, int64_t ldv,
+                   const double* a, int64_t lda, const double* fext, int64_t ldfext, double* tau,
+                   int64_t ldtau, int layout, int memspace, void* stream) {
+  return rnea_impl(m, B, q, ldq, v, ldv, a, lda, fext, ldfext, true, tau, ldtau, layout, memspace, stream);
+}
+
+static int aba_impl(brbd_model* m, int64_t B, const double* q, int64_t ldq, const double* v, int64_t ldv,
+                    const double* tau, int64_t ldtau, const double* fext, int64_t ldf, bool with_fext,
+                    double* ddq, int64_t ldddq, int layout, int memspace, void* stream) {
   int rc = check_common(m, B, layout, memspace);
   if (rc) return rc;
   const FlatModel& F = m->flat;
@@ -571,6 +593,7 @@ int brbd_aba(brbd_model* m, int64_t B, const double* q, int64_t ldq, const doubl
   if ((rc = check_mat("v", v, ldv, F.nv, B, layout))) return rc;
   // the reference forgets this check (algorithm/parallel/aba.hpp:62-69 tests `a` only); we add it
   if ((rc = check_mat("tau", tau, ldtau, F.nv, B, layout))) return rc;
+  if (with_fext && (rc = check_mat("fext", fext, ldf, 6 * (int64_t)F.njoints, B, layout))) return rc;
   if ((rc = check_mat("a", ddq, ldddq, F.nv, B, layout))) return rc;
   if (B == 0) return BRBD_OK;
   DevGuard dg(m->device);
@@ -578,15 +601,23 @@ int brbd_aba(brbd_model* m, int64_t B, const double* q, int64_t ldq, const doubl
   hipStream_t s = (hipStream_t)stream;
   KArgs A{};
   fill_common(m, A, B);
+  A.ldfext = ldf;
   if (memspace == BRBD_DEVICE) {
     A.q = q; A.ldq = ldq; A.v = v; A.ldv = ldv; A.a = tau; A.lda = ldtau; A.out = ddq; A.ldout = ldddq;
+    A.fext = with_fext ? fext : nullptr;
     return launch_algo(m, BRBD_ALGO_ABA, A, layout, s);
   }
   const size_t nq_ = mat_span(ldq, F.nq, B, layout), nv_ = mat_span(ldv, F.nv, B, layout),
-               nt_ = mat_span(ldtau, F.nv, B, layout), nd_ = mat_span(ldddq, F.nv, B, layout);
-  if ((rc = ensure_stage(m, padded(nq_) + padded(nv_) + padded(nt_) + padded(nd_)))) return rc;
+               nt_ = mat_span(ldtau, F.nv, B, layout), nd_ = mat_span(ldddq, F.nv, B, layout),
+               nf_ = with_fext ? mat_span(ldf, 6 * (int64_t)F.njoints, B, layout) : 0;
+  if ((rc = ensure_stage(m, padded(nq_) + padded(nv_) + padded(nt_) + padded(nd_) + padded(nf_)))) return rc;
   Staged st{m, s};
   double *dq = st.take(nq_), *dv = st.take(nv_), *dt = st.take(nt_), *dd = st.take(nd_);
+  if (with_fext) {
+    double* df = st.take(nf_);
+    HIP_TRY(hipMemcpyAsync(df, fext, nf_ * 8, hipMemcpyHostToDevice, s));
+    A.fext = df;
+  }
   HIP_TRY(hipMemcpyAsync(dq, q, nq_ * 8, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(dv, v, nv_ * 8, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(dt, tau, nt_ * 8, hipMemcpyHostToDevice, s));
@@ -597,6 +628,18 @@ int brbd_aba(brbd_model* m, int64_t B, const double* q, int64_t ldq, const doubl
   HIP_TRY(hipMemcpyAsync(ddq, dd, nd_ * 8, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   return BRBD_OK;
+}
+
+int brbd_aba(brbd_model* m, int64_t B, const double* q, int64_t ldq, const double* v, int64_t ldv,
+             const double* tau, int64_t ldtau, double* ddq, int64_t ldddq, int layout, int memspace,
+             void* stream) {
+  return aba_impl(m, B, q, ldq, v, ldv, tau, ldtau, nullptr, 0, false, ddq, ldddq, layout, memspace, stream);
+}
+
+int brbd_aba_fext(brbd_model* m, int64_t B, const double* q, int64_t ldq, const double* v, int64_t ldv,
+                  const double* tau, int64_t ldtau, const double* fext, int64_t ldfext, double* ddq,
+                  int64_t ldddq, int layout, int memspace, void* stream) {
+  return aba_impl(m, B, q, ldq, v, ldv, tau, ldtau, fext, ldfext, true, ddq, ldddq, layout, memspace, stream);
 }
 
 int brbd_fk_jacobians(brbd_model* m, int64_t B, const double* q, int64_t ldq, double* J, int64_t ldJ,

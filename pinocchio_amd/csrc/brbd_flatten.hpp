@@ -186,6 +186,7 @@ inline std::string flatten(const brbd_model_desc* d, FlatModel* out, int* status
     else if (children[p].size() == 1) fl |= F_CARRY_REGS;
     if (children[i].size() == 1) fl |= F_CARRY_IN;
     else fl |= F_MULTI;
+    if (M.tab_desc[i].jtype != M.tab[i].jtype) fl |= F_POST;
     fl |= bslot[i] << 16;
     op.flags = fl;
     M.prog.push_back(op);

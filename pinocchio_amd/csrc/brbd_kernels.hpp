@@ -46,11 +46,12 @@ struct KArgs {
   const double* a; int64_t lda;  // RNEA: a, ABA: tau
   double* out; int64_t ldout;    // RNEA: tau, ABA: ddq, FKJ: J
   double* out2; int64_t ldout2;  // FKJ: oMi
+  const double* fext; int64_t ldfext;  // external forces, 6 rows [lin; ang] per joint in its frame, or NULL
   const double* ctab;            // model-compiled kernels (brbd_spec.hpp): packed constant table
   int64_t tile0;                 //   first tile of this launch (the host launches in chunks)
   double* out3; int64_t ldout3;  //   RNEA derivatives: dtau/da
   double* out4; int64_t ldout4;  //   RNEA derivatives: tau
-  uint32_t nb[7];                //   bytes spanned by q, v, a/tau, out, out2, out3, out4 (0 = absent)
+  uint32_t nb[8];                //   bytes spanned by q, v, a/tau, out, out2, out3, out4, fext (0 = absent)
   uint32_t ws_bytes;             //   bytes of the global park area of this launch
 };
 
@@ -65,9 +66,16 @@ struct Mat<1> {  // BATCH_MAJOR: uniform row base (SGPR pair) + 32-bit lane offs
   double* p;     // base + tile * 64
   int64_t ld;
   unsigned lo8;  // clamped lane, in bytes (zero-extended 32-bit offset -> saddr addressing)
-  DI Mat(double* base, int64_t ld_, int64_t tile, int64_t B, int lane) : p(base + tile * WAVE), ld(ld_) {
+  int64_t t0;    // tile * 64
+  DI Mat(double* base, int64_t ld_, int64_t tile, int64_t B, int lane) : p(base + tile * WAVE), ld(ld_), t0(tile * WAVE) {
     const int64_t left = B - tile * WAVE;  // >= 1
     lo8 = ((int64_t)lane < left ? (unsigned)lane : (unsigned)(left - 1)) * 8u;
+  }
+  DI Mat other(const double* base, int64_t ld_) const {  // another matrix, same tile and lane
+    Mat m = *this;
+    m.p = const_cast<double*>(base) + t0;
+    m.ld = ld_;
+    return m;
   }
   DI double get(int d) const {
     return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(p + (int64_t)d * ld) + lo8);
@@ -79,14 +87,37 @@ struct Mat<1> {  // BATCH_MAJOR: uniform row base (SGPR pair) + 32-bit lane offs
 template <>
 struct Mat<0> {  // INSTANCE_MAJOR: per-lane row pointer, uniform element index
   double* row;
+  int64_t b;
   DI Mat(double* base, int64_t ld_, int64_t tile, int64_t B, int lane) {
-    int64_t b = tile * WAVE + lane;
+    b = tile * WAVE + lane;
     if (b >= B) b = B - 1;
     row = base + b * ld_;
+  }
+  DI Mat other(const double* base, int64_t ld_) const {  // another matrix, same instance
+    Mat m = *this;
+    m.row = const_cast<double*>(base) + b * ld_;
+    return m;
   }
   DI double get(int d) const { return row[d]; }
   DI void put(int d, double x) const { row[d] = x; }
 };
+
+// External force on the joint of `op`, in the frame the kernels use for it (rnea.hxx:205,
+// aba.hxx:338).  The caller gives it in the described joint frame; a canonicalised unaligned joint
+// (brbd_flatten.hpp) lives in that frame times Q, so the force is rotated by post = Q^T.
+template <class MatT>
+DI void load_fext(const KArgs& A, const Op op, const JointConst& jc, const MatT& like, double* f) {
+  const MatT fx = like.other(A.fext, A.ldfext);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) f[k] = fx.get(6 * op.joint + k);
+  if (op.flags & F_POST) {
+    double r[6];
+    rot_vec(jc.post, f, r);
+    rot_vec(jc.post, f + 3, r + 3);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) f[k] = r[k];
+  }
+}
 
 // ---- live-state storage policies -----------------------------------------------------------------
 // GlobalStore: slot s of this lane lives at base[s * 64 + lane]: one coalesced 512-byte row per
@@ -268,6 +299,11 @@ DI void rnea_step(const KArgs& A, const Op op, const Pre pre, Stack& S, const in
     force_cross(st.v, h, tmp);               // :75
 #pragma unroll
     for (int k = 0; k < 6; ++k) f[k] += tmp[k];
+    if (A.fext) {  // rnea.hxx:205
+      load_fext(A, op, jc, q, tmp);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) f[k] -= tmp[k];
+    }
     if (fl & F_PUSH_BRANCH) {
       const int base = VA0 + op_own_bslot(fl) * 12;
 #pragma unroll
@@ -411,13 +447,21 @@ DI void compose(bool root, const double* Rp, const double* tp, const double* Rl,
 }
 
 // own world inertia (packed sym6) and bias force of = ov x* (Y ov)  (aba.hxx:134-138)
-DI void aba_own_inertia(const JointConst& jc, const double* R, const double* t, const double* ov,
-                        double* Ia, double* of) {
+template <class MatT>
+DI void aba_own_inertia(const KArgs& A, const Op op, const MatT& q, const JointConst& jc, const double* R,
+                        const double* t, const double* ov, double* Ia, double* of) {
   double cw[3], Iw[6], h[6];
   inertia_to_world(R, t, jc.m, jc.c, jc.I, cw, Iw);
   inertia_to_sym6(jc.m, cw, Iw, Ia);
   inertia_mul(jc.m, cw, Iw, ov, h);
   force_cross(ov, h, of);
+  if (A.fext) {  // aba.hxx:338: of[i] -= oMi.act(fext[i])
+    double fe[6], fw[6];
+    load_fext(A, op, jc, q, fe);
+    se3_act_force(R, t, fe, fw);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) of[k] -= fw[k];
+  }
 }
 
 // live-state slots per lane (ABA), "stack" part (LDS first, see HybridStore):
@@ -692,7 +736,7 @@ DI void aba_step12(const KArgs& A, const Op op, const Pre pre, const AbaLayout L
     }
     if (fl & F_PUSH_BRANCH) {
       // accumulator starts with the joint's own inertia and bias force (aba.hxx:134-138)
-      aba_own_inertia(jc, st.R, st.t, st.ov, Ia, of);
+      aba_own_inertia(A, op, q, jc, st.R, st.t, st.ov, Ia, of);
       const int ac = L.acc0 + op_own_bslot(fl) * 27;
 #pragma unroll
       for (int k = 0; k < 21; ++k) S.st(ac + k, Ia[k]);
@@ -705,7 +749,7 @@ DI void aba_step12(const KArgs& A, const Op op, const Pre pre, const AbaLayout L
       S.st(L.sc0 + 2 * op.depth + 1, cs);
       return;
     }
-    aba_own_inertia(jc, st.R, st.t, st.ov, Ia, of);
+    aba_own_inertia(A, op, q, jc, st.R, st.t, st.ov, Ia, of);
   } else {
     // ---------------- backward visit of a non-leaf joint (aba.hxx:153-193) ----------------
     sn = S.ld(L.sc0 + 2 * op.depth);
@@ -719,7 +763,7 @@ DI void aba_step12(const KArgs& A, const Op op, const Pre pre, const AbaLayout L
 #pragma unroll
       for (int k = 0; k < 6; ++k) of[k] = S.ld(ac + 21 + k);
     } else {
-      aba_own_inertia(jc, st.R, st.t, st.ov, Ia, of);
+      aba_own_inertia(A, op, q, jc, st.R, st.t, st.ov, Ia, of);
 #pragma unroll
       for (int k = 0; k < 21; ++k) Ia[k] += st.cIa[k];  // aba.hxx:190-191 (single child)
 #pragma unroll

@@ -130,6 +130,8 @@ DI void spec_sincos(double x, double& so, double& co) {
 #define IN_Q(k) (mq.get(k, ldq8))
 #define IN_V(k) (mv.get(k, ldv8))
 #define IN_X(k) (mx.get(k, ldx8))
+// external forces: only in the kernel variants with WANT bit 5 (a compile-time constant)
+#define IN_F(k) ((WANT & 32) ? mf.get(k, ldf8) : 0.0)
 #define OUT(k, val) do { if (WANT & 1) mo.put(k, ldo8, val); } while (0)
 #define OUT2(k, val) do { if (WANT & 2) mo2.put(k, ldo28, val); } while (0)
 #define OUT3(k, val) do { if (WANT & 4) mo3.put(k, ldo38, val); } while (0)
@@ -187,6 +189,7 @@ DI void spec_sincos(double x, double& so, double& co) {
   const unsigned ldq8 = (unsigned)A.ldq * 8u, ldv8 = (unsigned)A.ldv * 8u, ldx8 = (unsigned)A.lda * 8u; \
   const unsigned ldo8 = (unsigned)A.ldout * 8u, ldo28 = (unsigned)A.ldout2 * 8u;                     \
   const unsigned ldo38 = (unsigned)A.ldout3 * 8u, ldo48 = (unsigned)A.ldout4 * 8u;                   \
+  const unsigned ldf8 = (unsigned)A.ldfext * 8u;                                                     \
   int trace_ix = 0;                                                                                  \
   (void)lds2; (void)wsr; (void)wsoff; (void)trace_ix;
 
@@ -200,6 +203,7 @@ DI void spec_sincos(double x, double& so, double& co) {
   const SpecMat<LAYOUT> mo2(A.out2, A.nb[4], ldo28, inst);                                           \
   const SpecMat<LAYOUT> mo3(A.out3, A.nb[5], ldo38, inst);                                           \
   const SpecMat<LAYOUT> mo4(A.out4, A.nb[6], ldo48, inst);                                           \
-  (void)mv; (void)mx; (void)mo; (void)mo2; (void)mo3; (void)mo4; (void)ldo38; (void)ldo48;
+  const SpecMat<LAYOUT> mf(A.fext, A.nb[7], ldf8, inst);                                             \
+  (void)mv; (void)mx; (void)mo; (void)mo2; (void)mo3; (void)mo4; (void)ldo38; (void)ldo48; (void)mf; (void)ldf8;
 
 }  // namespace brbd

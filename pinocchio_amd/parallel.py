@@ -202,6 +202,41 @@ def rneaInParallel(num_threads: int, pool: ModelPool, q, v, a, tau=None, device:
     return ret if tau is None or at.keep is ret else _copy_back(tau, at)
 
 
+def rnea(pool: ModelPool, q, v, a, fext, tau=None, device: Optional[int] = None):
+    """Batched ``pin.rnea(model, data, q, v, a, fext)`` (algorithm/rnea.hxx:171-219): ``fext`` is
+    (6 * njoints, B), rows 6i..6i+5 = the force [linear; angular] on joint i in its own frame
+    (entry 0, the universe's, is ignored like in the reference)."""
+    m = pool.getModel(0)
+    aq = _describe(q, m.nq, "q")
+    av, aa = _describe(v, m.nv, "v", aq.layout), _describe(a, m.nv, "a", aq.layout)
+    af = _describe(fext, 6 * m.njoints, "fext", aq.layout)
+    a0 = _same([aq, av, aa, af])
+    ret = tau if tau is not None else _alloc_like(q, a0, m.nv)
+    at = _describe(ret, m.nv, "tau", aq.layout)
+    _same([aq, at])
+    dm = pool.device_model(_device_of(a0, device))
+    capi.check(capi.lib().brbd_rnea_fext(dm.handle, a0.B, aq.ptr, aq.ld, av.ptr, av.ld, aa.ptr, aa.ld, af.ptr,
+                                         af.ld, at.ptr, at.ld, a0.layout, a0.space, _stream(a0)))
+    return ret if tau is None or at.keep is ret else _copy_back(tau, at)
+
+
+def aba(pool: ModelPool, q, v, tau, fext, a=None, device: Optional[int] = None):
+    """Batched ``pin.aba(model, data, q, v, tau, fext)``, WORLD convention (algorithm/aba.hxx:296-354);
+    ``fext`` as for :func:`rnea`."""
+    m = pool.getModel(0)
+    aq = _describe(q, m.nq, "q")
+    av, at = _describe(v, m.nv, "v", aq.layout), _describe(tau, m.nv, "tau", aq.layout)
+    af = _describe(fext, 6 * m.njoints, "fext", aq.layout)
+    a0 = _same([aq, av, at, af])
+    ret = a if a is not None else _alloc_like(q, a0, m.nv)
+    ad = _describe(ret, m.nv, "a", aq.layout)
+    _same([aq, ad])
+    dm = pool.device_model(_device_of(a0, device))
+    capi.check(capi.lib().brbd_aba_fext(dm.handle, a0.B, aq.ptr, aq.ld, av.ptr, av.ld, at.ptr, at.ld, af.ptr,
+                                        af.ld, ad.ptr, ad.ld, a0.layout, a0.space, _stream(a0)))
+    return ret if a is None or ad.keep is ret else _copy_back(a, ad)
+
+
 def abaInParallel(num_threads: int, pool: ModelPool, q, v, tau, a=None, device: Optional[int] = None):
     """``pin.abaInParallel(num_thread, pool, q, v, tau[, a])`` -> ddq (nv, B), WORLD convention
     (algorithm/parallel/aba.hpp:40-84)."""

@@ -59,6 +59,25 @@ def test_generated_derivative_bodies_match_oracle(model, dense):
         assert np.abs(x - r).max() / max(1.0, np.abs(r).max()) < 1e-12
 
 
+@pytest.mark.parametrize("model,dense", _models()[:2] + _models()[4:6], ids=lambda x: getattr(x, "name", str(x)))
+def test_generated_bodies_with_external_forces(model, dense):
+    """Kernel variants with WANT bit 5: rnea(q, v, a, fext) (rnea.hxx:205) and aba(q, v, tau, fext)
+    (aba.hxx:338).  Without the bit the very same text computes the plain algorithms."""
+    mv = joints.ModelView(model, dense=dense)
+    O = oracle.Oracle(model)
+    q, v, a = inputs(model, 6, 8)
+    f = np.random.default_rng(8).uniform(-2, 2, (6 * model.njoints, 6))
+    ref = O.rnea_fext(q, v, a, f)
+    assert np.abs(ref - O.rnea(q, v, a)).max() > 1e-2
+    tau = C.CpuKernel(mv, "rnea", want=33).run(q, v, a, (model.nv, 0, 0), fext=f)[0]
+    assert rel_err_cols(tau, ref).max() < 1e-12
+    ddq = C.CpuKernel(mv, "aba", want=33, reg_budget=8, lds_budget=20).run(q, v, ref, (model.nv, 0, 0), fext=f)[0]
+    assert rel_err_cols(ddq, O.aba_fext(q, v, ref, f)).max() < 1e-10
+    assert rel_err_cols(ddq, a).max() < 1e-9          # unittest/aba.cpp: aba(rnea(a, fext), fext) == a
+    tau0 = C.CpuKernel(mv, "rnea", want=1).run(q, v, a, (model.nv, 0, 0), fext=f)[0]
+    assert rel_err_cols(tau0, O.rnea(q, v, a)).max() < 1e-12
+
+
 def test_derivative_body_under_the_prezeroed_contract():
     """Without the structural zeros (rnea-derivatives.hpp:104-106: the caller zeroes the outputs)
     the body writes only coupled entries; on zeroed outputs the result is the same."""

@@ -370,6 +370,45 @@ def test_kernel_selection_pattern_dense_table(name):
     pool.release()
 
 
+@pytest.mark.parametrize("name", ["simple_humanoid", "quadruped", "arm7", "baxter_simple", "unaligned_tree"])
+def test_external_forces(torch_mod, name):
+    """brbd_rnea_fext / brbd_aba_fext (rnea.hxx:171-219, aba.hxx:296-354): compiled and table-driven
+    kernels, both layouts, host and device memory, against the oracle; aba(rnea(a, fext), fext) == a."""
+    torch = torch_mod
+    if name == "unaligned_tree":
+        model = S.random_tree(502, 10, kinds=[M.JOINT_RX, M.JOINT_REVOLUTE_UNALIGNED, M.JOINT_PRISMATIC_UNALIGNED,
+                                              M.JOINT_SPHERICAL, M.JOINT_REVOLUTE_UNBOUNDED_UNALIGNED])
+    else:
+        model = S.build(name)
+    pool = parallel.ModelPool(model, 1)
+    dm = pool.device_model(0)
+    O = oracle.Oracle(model)
+    B = 150
+    q, v, a = inputs(model, B, 31)
+    f = np.random.default_rng(31).uniform(-2, 2, (6 * model.njoints, B))
+    tau_ref = O.rnea_fext(q, v, a, f)
+    assert np.abs(tau_ref - O.rnea(q, v, a)).max() > 1e-2
+    for compiled in (True, False):
+        dm.use_compiled(compiled)
+        for order in "FC":
+            qq, vv, aa, ff, tt = (np.asarray(x, order=order) for x in (q, v, a, f, tau_ref))
+            tau = parallel.rnea(pool, qq, vv, aa, ff)
+            assert rel_err_cols(tau, tau_ref).max() < TOL_RNEA
+            ddq = parallel.aba(pool, qq, vv, tt, ff)
+            assert rel_err_cols(ddq, a).max() < TOL_ABA
+            # plain calls are unaffected by the variants
+            assert rel_err_cols(parallel.rneaInParallel(1, pool, qq, vv, aa), O.rnea(q, v, a)).max() < TOL_RNEA
+    dm.use_compiled(True)
+    dev = torch.device("cuda", 0)
+    qd, vd, ad, fd = (torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (q, v, a, f))
+    taud = parallel.rnea(pool, qd, vd, ad, fd)
+    ddqd = parallel.aba(pool, qd, vd, taud, fd)
+    torch.cuda.synchronize()
+    assert rel_err_cols(taud.cpu().numpy(), tau_ref).max() < TOL_RNEA
+    assert rel_err_cols(ddqd.cpu().numpy(), a).max() < TOL_ABA
+    pool.release()
+
+
 @pytest.mark.parametrize("seed", [0, 1, 2, 3])
 def test_unaligned_joints(seed):
     """RevoluteUnaligned / PrismaticUnaligned (joint-revolute-unaligned.hpp:667-708): the flattener

@@ -155,3 +155,26 @@ def test_batched_equals_serial_bitwise():
     tau_p, tau_s = O.rnea(q, v, a, threads=th), O.rnea(q, v, a, threads=1)
     assert np.array_equal(tau_p, tau_s)
     assert np.array_equal(O.aba(q, v, tau_p, threads=th), O.aba(q, v, tau_s, threads=1))
+
+
+def test_external_forces_world_and_local_aba_agree_and_invert_rnea():
+    """unittest/aba.cpp (test_aba_with_fext): aba(q, v, rnea(q, v, a, fext), fext) == a, in both
+    conventions; zero forces give the plain algorithms; rnea is affine in fext."""
+    import numpy as np
+    import oracle
+    from pinocchio_amd import sample_models as S
+    from util import inputs
+    for m in (S.simple_humanoid(), S.random_tree(11, 10), S.arm7()):
+        O = oracle.Oracle(m)
+        q, v, a = inputs(m, 7, 5)
+        rng = np.random.default_rng(5)
+        f1, f2 = (rng.uniform(-3, 3, (6 * m.njoints, 7)) for _ in range(2))
+        tau = O.rnea_fext(q, v, a, f1)
+        assert np.abs(O.aba_fext(q, v, tau, f1) - a).max() < 1e-9
+        assert np.abs(O.aba_fext(q, v, tau, f1, "local") - a).max() < 1e-9
+        assert np.abs(O.rnea_fext(q, v, a, 0 * f1) - O.rnea(q, v, a)).max() == 0.0
+        lin = O.rnea_fext(q, v, a, f1 + f2) - O.rnea_fext(q, v, a, f1) - O.rnea_fext(q, v, a, f2) + O.rnea(q, v, a)
+        assert np.abs(lin).max() < 1e-10
+        # the universe's entry is ignored
+        f3 = f1.copy(); f3[:6] = 99.0
+        assert np.abs(O.rnea_fext(q, v, a, f3) - tau).max() == 0.0

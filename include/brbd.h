@@ -174,6 +174,14 @@ int brbd_aba_fext(brbd_model* m, int64_t B, const double* q, int64_t ldq, const 
 int brbd_fk_jacobians(brbd_model* m, int64_t B, const double* q, int64_t ldq, double* J, int64_t ldJ,
                       double* oMi, int64_t ldoMi, int layout, int memspace, void* stream);
 
+/* computeJointJacobians(q) followed by getJointJacobian(joint, rf, J) per instance
+ * (algorithm/jacobian.hxx:38-95, 175-283, 315-326): J is (6 * nv) x B, per instance a column-major
+ * 6 x nv matrix; the columns of the joint's support (the joint and its ancestors) hold the joint
+ * Jacobian expressed in rf (pinocchio::ReferenceFrame: 0 WORLD, 1 LOCAL, 2 LOCAL_WORLD_ALIGNED),
+ * every other column is written as zero (the reference leaves them to the caller's setZero()). */
+int brbd_joint_jacobian(brbd_model* m, int64_t B, const double* q, int64_t ldq, int joint, int rf,
+                        double* J, int64_t ldJ, int layout, int memspace, void* stream);
+
 /* computeRNEADerivatives (algorithm/rnea-derivatives.hxx:472-541) for B
  * instances.  Each output is nv x nv column-major per instance (element (r,c)
  * at offset c*nv + r), in the two layouts above with dof = nv*nv.  Unlike the

@@ -40,6 +40,7 @@ def lib():
         L.brbd_oracle_aba_local.argtypes = [vp, dp, dp, dp, dp]
         L.brbd_oracle_rnea_fext.argtypes = [vp, dp, dp, dp, dp, dp]
         L.brbd_oracle_aba_fext.argtypes = [vp, dp, dp, dp, dp, ctypes.c_int, dp]
+        L.brbd_oracle_joint_jacobian.argtypes = [vp, dp, ctypes.c_int, ctypes.c_int, dp]
         L.brbd_oracle_fk_jacobians.argtypes = [vp, dp, dp, dp]
         L.brbd_oracle_rnea_derivatives.argtypes = [vp, dp, dp, dp, dp, dp, dp, dp]
         i64 = ctypes.c_int64
@@ -119,6 +120,16 @@ class Oracle:
             assert rc == 0, rc
             ddq[:, b] = out
         return ddq
+
+    def joint_jacobian(self, q, joint, rf):
+        """getJointJacobian(joint, rf) per column: (6*nv, B); rf 0 WORLD, 1 LOCAL, 2 LOCAL_WORLD_ALIGNED."""
+        q = _cols(q, self.nq)
+        J = np.zeros((6 * self.nv, q.shape[1]), order="F")
+        for b in range(q.shape[1]):
+            qb, out = np.ascontiguousarray(q[:, b]), np.zeros(6 * self.nv)
+            assert lib().brbd_oracle_joint_jacobian(self._ref, _p(qb), joint, rf, _p(out)) == 0
+            J[:, b] = out
+        return J
 
     def fk_jacobians(self, q, threads=1):
         """Returns J (6*nv, B) [per instance 6 x nv column-major] and oMi (12*njoints, B)."""

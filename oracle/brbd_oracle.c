@@ -1147,6 +1147,37 @@ int brbd_oracle_aba_fext(const brbd_model_desc* m, const double* q, const double
   ws_free(w);
   return rc;
 }
+/* computeJointJacobians (jacobian.hxx:38-95) + getJointJacobian(joint, rf) (:175-283,315-326):
+ * the columns of the joint's support (itself and its ancestors) of the world Jacobian, expressed
+ * in rf: 0 WORLD (copied), 1 LOCAL (oMjoint.actInv), 2 LOCAL_WORLD_ALIGNED (linear -= t x angular);
+ * J is 6 x nv column-major and must come zeroed (the other columns are not written). */
+int brbd_oracle_joint_jacobian(const brbd_model_desc* m, const double* q, int joint, int rf, double* J) {
+  if (check_model(m) || joint < 1 || joint >= m->njoints || rf < 0 || rf > 2) return -1;
+  ws_t* w = ws_alloc(m);
+  double* Jw = (double*)calloc((size_t)6 * m->nv + 6, sizeof(double));
+  fkjac_ws(m, w, q, Jw, NULL);
+  const se3_t* oM = &w->oMi[joint];
+  for (int i = joint; i > 0; i = m->parents[i])
+    for (int c = 0; c < JOINT_NV[m->jtype[i]]; ++c) {
+      const double* in = Jw + 6 * (m->idx_v[i] + c);
+      double* out = J + 6 * (m->idx_v[i] + c);
+      if (rf == 0) {
+        memcpy(out, in, 6 * sizeof(double));
+      } else if (rf == 1) {
+        se3_actinv_motion(oM, in, out);
+      } else {
+        double tx[3];
+        cross3(oM->t, in + 3, tx);
+        for (int k = 0; k < 3; ++k) {
+          out[k] = in[k] - tx[k];
+          out[3 + k] = in[3 + k];
+        }
+      }
+    }
+  free(Jw);
+  ws_free(w);
+  return 0;
+}
 int brbd_oracle_fk_jacobians(const brbd_model_desc* m, const double* q, double* J, double* oMi) {
   if (check_model(m)) return -1;
   ws_t* w = ws_alloc(m);

@@ -43,6 +43,9 @@ int brbd_oracle_rnea_fext(const brbd_model_desc* m, const double* q, const doubl
                           const double* fext, double* tau);
 int brbd_oracle_aba_fext(const brbd_model_desc* m, const double* q, const double* v, const double* tau,
                          const double* fext, int convention, double* ddq);
+/* getJointJacobian after computeJointJacobians (jacobian.hxx:175-283): rf 0 WORLD, 1 LOCAL,
+ * 2 LOCAL_WORLD_ALIGNED; J (6 x nv, column-major) must be zeroed by the caller */
+int brbd_oracle_joint_jacobian(const brbd_model_desc* m, const double* q, int joint, int rf, double* J);
 int brbd_oracle_fk_jacobians(const brbd_model_desc* m, const double* q, double* J, double* oMi);
 /* algorithm/rnea-derivatives.hxx:472-541.  Outputs nv x nv column-major, fully
  * written (zeros included); dtau_da upper triangle only.  dtau_da / tau may be NULL. */

@@ -27,12 +27,14 @@ HOST = 0
 DEVICE = 1
 
 ALGO_RNEA, ALGO_ABA, ALGO_FK_JAC, ALGO_RNEA_DERIV = 0, 1, 2, 3
+# pinocchio::ReferenceFrame (multibody/fwd.hpp:46-54)
+WORLD, LOCAL, LOCAL_WORLD_ALIGNED = 0, 1, 2
 
 # every extern "C" symbol of include/brbd.h (checked by tests/test_capi_symbols.py)
 SYMBOLS = (
     "brbd_last_error", "brbd_version", "brbd_device_count",
     "brbd_model_create", "brbd_model_destroy", "brbd_model_dims", "brbd_workspace_bytes",
-    "brbd_rnea", "brbd_aba", "brbd_rnea_fext", "brbd_aba_fext", "brbd_fk_jacobians", "brbd_rnea_derivatives",
+    "brbd_rnea", "brbd_aba", "brbd_rnea_fext", "brbd_aba_fext", "brbd_fk_jacobians", "brbd_joint_jacobian", "brbd_rnea_derivatives",
     "brbd_transpose_to_batch_major", "brbd_transpose_to_instance_major",
     "brbd_set_timing", "brbd_kernel_time", "brbd_model_compiled_kernels", "brbd_model_use_compiled", "brbd_model_outputs_prezeroed", "brbd_model_canonical_form",
 )
@@ -125,6 +127,8 @@ def lib():
     L.brbd_aba_fext.argtypes = [vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, ci, ci, vp]
     L.brbd_fk_jacobians.restype = ci
     L.brbd_fk_jacobians.argtypes = [vp, i64, vp, i64, vp, i64, vp, i64, ci, ci, vp]
+    L.brbd_joint_jacobian.restype = ci
+    L.brbd_joint_jacobian.argtypes = [vp, i64, vp, i64, ci, ci, vp, i64, ci, ci, vp]
     L.brbd_rnea_derivatives.restype = ci
     L.brbd_rnea_derivatives.argtypes = [vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64,
                                         vp, i64, ci, ci, vp]

@@ -200,6 +200,8 @@ class Emitter:
         """vals - thunk() in the kernel variants whose WANT mask has ``bit`` (external forces),
         vals unchanged in the others: the statements thunk() emits sit in an ``if (WANT & bit)``
         block, a compile-time constant in every instantiation."""
+        if os.environ.get("BRBD_CG_NOFEXT") == "1":  # experiment hook: bodies without the blocks
+            return list(vals)
         names = []
         for v in vals:
             n = self._tmp()

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -66,6 +67,8 @@ struct brbd_model {
   // per-algorithm launch geometry (waves resident on the device)
   int max_waves[4] = {0, 0, 0, 0};
   int max_waves_spec[4] = {0, 0, 0, 0};
+  int max_waves_jjac = 0;
+  std::map<int, std::pair<Op*, int>> chains;  // brbd_joint_jacobian: support chain of a joint (device)
   // model-compiled kernels (brbd_spec.hpp), when the model's signature is registered
   const SpecEntry* spec = nullptr;
   double* d_ct[4] = {nullptr, nullptr, nullptr, nullptr};  // packed constant table per algorithm
@@ -472,6 +475,7 @@ int brbd_model_create(const brbd_model_desc* desc, int device, brbd_model** out)
 int brbd_model_destroy(brbd_model* m) {
   if (!m) return BRBD_OK;
   DevGuard dg(m->device);
+  for (auto& c : m->chains) (void)hipFree(c.second.first);
   for (auto& v : m->timed) v.clear();  // (events are destroyed with their last holder)
   m->last_stop.reset();
   if (m->d_tab) (void)hipFree(m->d_tab);
@@ -675,6 +679,70 @@ int brbd_fk_jacobians(brbd_model* m, int64_t B, const double* q, int64_t ldq, do
   if ((rc = launch_algo(m, BRBD_ALGO_FK_JAC, A, layout, s))) return rc;
   if (J) HIP_TRY(hipMemcpyAsync(J, dJ, nj_ * 8, hipMemcpyDeviceToHost, s));
   if (oMi) HIP_TRY(hipMemcpyAsync(oMi, dM, nm_ * 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return BRBD_OK;
+}
+
+int brbd_joint_jacobian(brbd_model* m, int64_t B, const double* q, int64_t ldq, int joint, int rf,
+                        double* J, int64_t ldJ, int layout, int memspace, void* stream) {
+  int rc = check_common(m, B, layout, memspace);
+  if (rc) return rc;
+  const FlatModel& F = m->flat;
+  if (joint < 1 || joint >= F.njoints) return fail(BRBD_ERR_INVALID_ARGUMENT, "joint index out of range");
+  if (rf < 0 || rf > 2) return fail(BRBD_ERR_INVALID_ARGUMENT, "rf must be 0 (WORLD), 1 (LOCAL) or 2 (LOCAL_WORLD_ALIGNED)");
+  const int64_t jd = 6 * (int64_t)F.nv;
+  if ((rc = check_mat("q", q, ldq, F.nq, B, layout))) return rc;
+  if ((rc = check_mat("J", J, ldJ, jd, B, layout))) return rc;
+  if (B == 0) return BRBD_OK;
+  DevGuard dg(m->device);
+  if (!dg.ok) return fail(BRBD_ERR_RUNTIME, "hipSetDevice failed");
+  hipStream_t s = (hipStream_t)stream;
+  // support chain of the joint, root first, as forward ops (cached per joint)
+  Op* d_chain = nullptr;
+  int nchain = 0;
+  {
+    std::lock_guard<std::mutex> g(m->mu);
+    auto it = m->chains.find(joint);
+    if (it == m->chains.end()) {
+      std::vector<Op> chain;
+      for (int i = joint; i > 0; i = F.tab[i].parent) {
+        Op op{};
+        for (const Op& o : F.prog3)
+          if (o.joint == i) op = o;
+        chain.insert(chain.begin(), op);
+      }
+      Op* d = nullptr;
+      HIP_TRY(hipMalloc(&d, chain.size() * sizeof(Op)));
+      HIP_TRY(hipMemcpy(d, chain.data(), chain.size() * sizeof(Op), hipMemcpyHostToDevice));
+      it = m->chains.emplace(joint, std::make_pair(d, (int)chain.size())).first;
+    }
+    d_chain = it->second.first;
+    nchain = it->second.second;
+  }
+  KArgs A{};
+  fill_common(m, A, B);
+  A.prog3 = d_chain;
+  A.nops3 = nchain;
+  A.rf = rf;
+  auto run = [&](const double* dq, double* dJ) -> int {
+    A.q = dq; A.ldq = ldq; A.out = dJ; A.ldout = ldJ;
+    if (m->max_waves_jjac == 0) m->max_waves_jjac = resident_waves(m, jjac_kernel<1>, WAVE);
+    const int64_t grid = A.ntiles < m->max_waves_jjac ? A.ntiles : m->max_waves_jjac;
+    const dim3 g((unsigned)grid), b(WAVE);
+    if (layout == BRBD_BATCH_MAJOR) hipLaunchKernelGGL(jjac_kernel<1>, g, b, 0, s, A);
+    else hipLaunchKernelGGL(jjac_kernel<0>, g, b, 0, s, A);
+    HIP_TRY(hipGetLastError());
+    return BRBD_OK;
+  };
+  if (memspace == BRBD_DEVICE) return run(q, J);
+  const size_t nq_ = mat_span(ldq, F.nq, B, layout), nj_ = mat_span(ldJ, jd, B, layout);
+  if ((rc = ensure_stage(m, padded(nq_) + padded(nj_)))) return rc;
+  Staged st{m, s};
+  double *dq = st.take(nq_), *dJ = st.take(nj_);
+  HIP_TRY(hipMemcpyAsync(dq, q, nq_ * 8, hipMemcpyHostToDevice, s));
+  if (ldJ != (layout == BRBD_BATCH_MAJOR ? B : jd)) HIP_TRY(hipMemcpyAsync(dJ, J, nj_ * 8, hipMemcpyHostToDevice, s));
+  if ((rc = run(dq, dJ))) return rc;
+  HIP_TRY(hipMemcpyAsync(J, dJ, nj_ * 8, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   return BRBD_OK;
 }

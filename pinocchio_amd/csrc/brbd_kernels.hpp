@@ -38,7 +38,7 @@ struct KArgs {
   int64_t ntiles;
   double* ws;         // spill workspace
   int32_t lds_cap;    // live-state slots held in LDS (HybridStore), rest in ws
-  int32_t pad_;
+  int32_t rf;         // jjac_kernel: reference frame
   int64_t ws_stride;  // doubles per wave
   double gx, gy, gz;  // gravity
   const double* q; int64_t ldq;
@@ -1104,6 +1104,82 @@ __global__ __launch_bounds__(WAVE) void fkjac_kernel(const KArgs A) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) st.t[k] = 0.0;
     for (int s = 0; s < A.nops3; ++s) fkjac_step(A, load_op(A.prog3, s), S, q, Jout, Mout, wantJ, wantM, st);
+  }
+}
+
+// ============================================================================ joint Jacobian
+// computeJointJacobians + getJointJacobian(joint, rf) (jacobian.hxx:38-95,175-283) for ONE joint:
+// A.prog3 holds the joint's support chain, root first (A.nops3 entries); A.rf = 0 WORLD, 1 LOCAL,
+// 2 LOCAL_WORLD_ALIGNED.  Two walks over the chain: the first for the joint's placement, the
+// second writes each support column in the requested frame; the other columns are zero.
+template <int NV, class MatT>
+DI void jjac_put(int rf, const double* Rj, const double* tj, const double* J, int idx_v, const MatT& Jout) {
+#pragma unroll
+  for (int c = 0; c < NV; ++c) {
+    const double* col = J + 6 * c;
+    double o[6];
+    if (rf == 1) {          // LOCAL: oMjoint.actInv(col)
+      se3_actinv_motion(Rj, tj, col, o);
+    } else if (rf == 2) {   // LOCAL_WORLD_ALIGNED: linear -= t x angular
+      double tx[3];
+      cross3(tj, col + 3, tx);
+      o[0] = col[0] - tx[0]; o[1] = col[1] - tx[1]; o[2] = col[2] - tx[2];
+      o[3] = col[3]; o[4] = col[4]; o[5] = col[5];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) o[k] = col[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) Jout.put(6 * (idx_v + c) + k, o[k]);
+  }
+}
+
+template <int LAYOUT>
+__global__ __launch_bounds__(WAVE) void jjac_kernel(const KArgs A) {
+  const int lane = threadIdx.x;
+  for (int64_t tile = blockIdx.x; tile < A.ntiles; tile += gridDim.x) {
+    const Mat<LAYOUT> q(const_cast<double*>(A.q), A.ldq, tile, A.B, lane);
+    const Mat<LAYOUT> Jout(A.out, A.ldout, tile, A.B, lane);
+    for (int k = 0; k < 6 * A.nv; ++k) Jout.put(k, 0.0);
+    double Rj[9], tj[3];
+    for (int pass = 0; pass < 2; ++pass) {
+      double R[9], t[3];
+      for (int s = 0; s < A.nops3; ++s) {
+        const Op op = load_op(A.prog3, s);
+        JointConst jc;
+        load_joint(A.tab, op.joint, jc);
+        double Rl[9], tl[3], sn, cs, Rn[9], tn[3];
+        joint_liMi(jc, op, q, q.get(op.idx_q), false, sn, cs, Rl, tl);
+        compose(s == 0, R, t, Rl, tl, Rn, tn);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) R[k] = Rn[k];
+        t[0] = tn[0]; t[1] = tn[1]; t[2] = tn[2];
+        if (pass == 0) {
+          if (s == A.nops3 - 1) {  // the joint itself
+            if (op.flags & F_POST) rot_mul(R, jc.post, Rj);  // described frame of a canonicalised joint
+            else {
+#pragma unroll
+              for (int k = 0; k < 9; ++k) Rj[k] = R[k];
+            }
+            tj[0] = t[0]; tj[1] = t[1]; tj[2] = t[2];
+          }
+          continue;
+        }
+        if (op.nvj == 1) {
+          double J[6];
+          jcol_1dof(op, R, t, J);
+          jjac_put<1>(A.rf, Rj, tj, J, op.idx_v, Jout);
+        } else if (op.nvj == 6) {
+          double J[36];
+          jcols_multi<6>(R, t, J);
+          jjac_put<6>(A.rf, Rj, tj, J, op.idx_v, Jout);
+        } else {
+          double J[18];
+          jcols_multi<3>(R, t, J);
+          jjac_put<3>(A.rf, Rj, tj, J, op.idx_v, Jout);
+        }
+      }
+    }
   }
 }
 

@@ -290,6 +290,21 @@ def forwardKinematics(pool: ModelPool, q, device: Optional[int] = None):
     return oMi
 
 
+def getJointJacobian(pool: ModelPool, q, joint_id: int, reference_frame: int = capi.LOCAL,
+                     device: Optional[int] = None):
+    """Batched ``computeJointJacobians(q)`` + ``getJointJacobian(joint_id, reference_frame)``
+    (algorithm/jacobian.hxx:38-95, 175-283): (6*nv, B), per instance a column-major 6 x nv matrix.
+    ``reference_frame``: capi.WORLD / LOCAL / LOCAL_WORLD_ALIGNED."""
+    m = pool.getModel(0)
+    aq = _describe(q, m.nq, "q")
+    J = _alloc_like(q, aq, 6 * m.nv)
+    aj = _describe(J, 6 * m.nv, "J", aq.layout)
+    dm = pool.device_model(_device_of(aq, device))
+    capi.check(capi.lib().brbd_joint_jacobian(dm.handle, aq.B, aq.ptr, aq.ld, int(joint_id), int(reference_frame),
+                                              aj.ptr, aj.ld, aq.layout, aq.space, _stream(aq)))
+    return J
+
+
 def computeRNEADerivatives(pool: ModelPool, q, v, a, want_tau: bool = False, device: Optional[int] = None,
                            out=None):
     """Batched ``computeRNEADerivatives`` (algorithm/rnea-derivatives.hxx:472-541): returns

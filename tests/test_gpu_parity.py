@@ -409,6 +409,31 @@ def test_external_forces(torch_mod, name):
     pool.release()
 
 
+@pytest.mark.parametrize("name", ["simple_humanoid", "arm7", "unaligned_tree"])
+def test_joint_jacobian(name):
+    """brbd_joint_jacobian = computeJointJacobians + getJointJacobian(joint, rf)
+    (jacobian.hxx:38-95, 175-283) in the three reference frames, both layouts, against the oracle."""
+    if name == "unaligned_tree":
+        model = S.random_tree(503, 10, kinds=[M.JOINT_RY, M.JOINT_REVOLUTE_UNALIGNED, M.JOINT_PRISMATIC_UNALIGNED,
+                                              M.JOINT_SPHERICAL, M.JOINT_REVOLUTE_UNBOUNDED_UNALIGNED])
+    else:
+        model = S.build(name)
+    pool = parallel.ModelPool(model, 1)
+    O = oracle.Oracle(model)
+    q, _, _ = inputs(model, 100, 41)
+    for joint in (1, model.njoints // 2, model.njoints - 1):
+        for rf in (capi.WORLD, capi.LOCAL, capi.LOCAL_WORLD_ALIGNED):
+            ref = O.joint_jacobian(q, joint, rf)
+            for order in "FC":
+                J = parallel.getJointJacobian(pool, np.asarray(q, order=order), joint, rf)
+                assert np.abs(J - ref).max() < TOL_KIN, (joint, rf, order)
+    with pytest.raises(capi.BrbdInvalidArgument):
+        parallel.getJointJacobian(pool, q, model.njoints, capi.LOCAL)
+    with pytest.raises(capi.BrbdInvalidArgument):
+        parallel.getJointJacobian(pool, q, 1, 3)
+    pool.release()
+
+
 @pytest.mark.parametrize("seed", [0, 1, 2, 3])
 def test_unaligned_joints(seed):
     """RevoluteUnaligned / PrismaticUnaligned (joint-revolute-unaligned.hpp:667-708): the flattener

@@ -178,3 +178,35 @@ def test_external_forces_world_and_local_aba_agree_and_invert_rnea():
         # the universe's entry is ignored
         f3 = f1.copy(); f3[:6] = 99.0
         assert np.abs(O.rnea_fext(q, v, a, f3) - tau).max() == 0.0
+
+
+def test_joint_jacobian_frames_are_consistent():
+    """unittest/joint-jacobian.cpp:39-57: WORLD columns = the support columns of the full Jacobian;
+    LOCAL = oMi.actInv(WORLD); LOCAL_WORLD_ALIGNED = rotation of LOCAL into the world basis; the
+    LOCAL Jacobian times v is the joint's spatial velocity (here: RNEA-free check through the
+    velocity recursion of the naive implementation is replaced by J_world v == oMi.act(J_local v))."""
+    import numpy as np
+    import oracle
+    from pinocchio_amd import sample_models as S
+    from util import inputs
+    for m in (S.simple_humanoid(), S.random_tree(21, 10)):
+        O = oracle.Oracle(m)
+        q, v, _ = inputs(m, 4, 2)
+        Jfull, oMi = O.fk_jacobians(q)
+        for j in (1, m.njoints // 2, m.njoints - 1):
+            Jw, Jl, Ja = (O.joint_jacobian(q, j, rf) for rf in (0, 1, 2))
+            support = []
+            i = j
+            while i > 0:
+                support += list(range(m.idx_vs[i], m.idx_vs[i] + m.nvs[i]))
+                i = m.parents[i]
+            for b in range(4):
+                W, L, A_ = (x[:, b].reshape(m.nv, 6).T for x in (Jw, Jl, Ja))
+                F = Jfull[:, b].reshape(m.nv, 6).T
+                other = [c for c in range(m.nv) if c not in support]
+                assert np.abs(W[:, support] - F[:, support]).max() == 0.0 and np.abs(W[:, other]).max() == 0.0
+                R = oMi[12 * j:12 * j + 9, b].reshape(3, 3).T
+                t = oMi[12 * j + 9:12 * j + 12, b]
+                assert np.abs(np.vstack([R @ L[:3], R @ L[3:]]) - A_).max() < 1e-12
+                back = np.vstack([R @ L[:3] + np.cross(t, (R @ L[3:]).T).T, R @ L[3:]])   # oMi.act(LOCAL)
+                assert np.abs(back - W).max() < 1e-12

@@ -22,7 +22,7 @@ def timed(dm, algo, fn, reps):
     n, ms = dm.kernel_time(algo)
     return ms / max(n, 1) * 1e-3 * (n / reps)   # seconds per call (chunked launches summed)
 
-which = sys.argv[1:] or ["fkjac", "aba", "rnea", "deriv"]
+which = sys.argv[1:] or ["fkjac", "aba", "rnea", "deriv", "fext", "jjac"]
 if "fkjac" in which:
     m = S.arm7(); B = 1 << 20; pool = parallel.ModelPool(m, 1); dm = pool.device_model(0)
     q, _, _ = inputs(m, B)
@@ -56,5 +56,29 @@ if "deriv" in which:
     outs = [torch.zeros((m.nv * m.nv, B), dtype=torch.float64, device="cuda") for _ in range(3)]
     t = timed(dm, capi.ALGO_RNEA_DERIV, lambda: parallel.computeRNEADerivatives(pool, q, v, a, out=outs), 5)
     print(json.dumps({"config": "quadruped RNEA derivatives B=262144, outputs pre-zeroed by the caller",
+                      "s_per_call": t, "evals_per_s": B / t, "GBps_algorithmic": byts / t / 1e9}))
+    pool.release()
+
+if "fext" in which:   # simple_humanoid with external forces (rnea.hxx:171-219, aba.hxx:296-354)
+    m = S.simple_humanoid(); B = 1 << 16; pool = parallel.ModelPool(m, 1); dm = pool.device_model(0)
+    q, v, a = inputs(m, B)
+    f = torch.from_numpy(np.random.default_rng(1).uniform(-1, 1, (6 * m.njoints, B))).cuda()
+    tau = torch.empty_like(a); ddq = torch.empty_like(a)
+    tr = timed(dm, capi.ALGO_RNEA, lambda: parallel.rnea(pool, q, v, a, f, tau), 20)
+    ta = timed(dm, capi.ALGO_ABA, lambda: parallel.aba(pool, q, v, tau, f, ddq), 20)
+    byts = (m.nq + 3 * m.nv + 6 * m.njoints) * 8 * B
+    print(json.dumps({"config": "simple_humanoid RNEA / ABA with external forces B=65536", "rnea_s": tr, "aba_s": ta,
+                      "rnea_evals_per_s": B / tr, "aba_evals_per_s": B / ta, "rnea_GBps_algorithmic": byts / tr / 1e9}))
+    pool.release()
+if "jjac" in which:   # arm7 end-effector Jacobian, LOCAL_WORLD_ALIGNED
+    m = S.arm7(); B = 1 << 20; pool = parallel.ModelPool(m, 1); dm = pool.device_model(0)
+    q, _, _ = inputs(m, B)
+    import time
+    for _ in range(3): parallel.getJointJacobian(pool, q, m.njoints - 1, capi.LOCAL_WORLD_ALIGNED)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(10): parallel.getJointJacobian(pool, q, m.njoints - 1, capi.LOCAL_WORLD_ALIGNED)
+    torch.cuda.synchronize(); t = (time.perf_counter() - t0) / 10
+    byts = (m.nq + 6 * m.nv) * 8 * B
+    print(json.dumps({"config": "arm7 getJointJacobian(last joint, LOCAL_WORLD_ALIGNED) B=1048576 (wall time per call)",
                       "s_per_call": t, "evals_per_s": B / t, "GBps_algorithmic": byts / t / 1e9}))
     pool.release()

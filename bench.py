@@ -116,6 +116,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # the GPU's clocks take a few hundred ms of load to settle (step time 75 -> 68 us): run the step
+    # for 0.3 s before the W warm-up steps, so that short --steps / --warmup runs measure the same
+    # machine state as long ones
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < 0.3:
+        for _ in range(50):
+            step()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     fence()

@@ -5,7 +5,7 @@ sys.path.insert(0, '.')
 from pinocchio_amd import parallel, capi, sample_models as S
 for name in ("manipulator", "arm7", "simple_humanoid"):
     m = S.build(name)
-    for B in (64, 4096, 65536):
+    for B in ((64, 4096, 65536) if name != "simple_humanoid" else (64, 4096, 32768, 65536, 131072, 262144, 1048576)):
         rng = np.random.default_rng(0)
         q = torch.from_numpy(np.ascontiguousarray(m.random_configuration(rng, B))).cuda()
         v = torch.from_numpy(rng.uniform(-1, 1, (m.nv, B))).cuda()

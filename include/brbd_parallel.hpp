@@ -123,6 +123,56 @@ void abaInParallel(const size_t num_threads, ModelPool& pool, const ConfigPool& 
                         BRBD_HOST, nullptr));
 }
 
+// Batched rnea(model, data, q, v, a, fext) / aba(model, data, q, v, tau, fext) (algorithm/rnea.hxx:171-219,
+// algorithm/aba.hxx:296-354, WORLD convention): `fext` is (6 * njoints) x B, column b holding the
+// reference's aligned_vector<Force> of instance b, entry i = [linear; angular] in joint i's frame.
+template <class ConfigPool, class Tangent1, class Tangent2, class ForcePool, class Tangent3>
+void rnea(ModelPool& pool, const ConfigPool& q, const Tangent1& v, const Tangent2& a, const ForcePool& fext,
+          const Tangent3& tau) {
+  detail::check(pool.size() > 0, "The pool should have at least one element");
+  const ModelDesc& m = pool.getModel(0);
+  detail::check(q.rows() == m.nq, "q.rows() != model.nq");
+  detail::check(v.rows() == m.nv && a.rows() == m.nv && tau.rows() == m.nv, "rows != model.nv");
+  detail::check(fext.rows() == 6 * m.njoints, "fext.rows() != 6 * model.njoints");  // rnea.hxx:179
+  detail::check(q.cols() == v.cols() && q.cols() == a.cols() && q.cols() == tau.cols() && q.cols() == fext.cols(),
+                "column mismatch");
+  throw_status(brbd_rnea_fext(pool.handle(), (int64_t)q.cols(), q.data(), (int64_t)q.outerStride(), v.data(),
+                              (int64_t)v.outerStride(), a.data(), (int64_t)a.outerStride(), fext.data(),
+                              (int64_t)fext.outerStride(), const_cast<double*>(tau.data()),
+                              (int64_t)tau.outerStride(), BRBD_INSTANCE_MAJOR, BRBD_HOST, nullptr));
+}
+
+template <class ConfigPool, class Tangent1, class Tangent2, class ForcePool, class Tangent3>
+void aba(ModelPool& pool, const ConfigPool& q, const Tangent1& v, const Tangent2& tau, const ForcePool& fext,
+         const Tangent3& a) {
+  detail::check(pool.size() > 0, "The pool should have at least one element");
+  const ModelDesc& m = pool.getModel(0);
+  detail::check(q.rows() == m.nq, "q.rows() != model.nq");
+  detail::check(v.rows() == m.nv && a.rows() == m.nv && tau.rows() == m.nv, "rows != model.nv");
+  detail::check(fext.rows() == 6 * m.njoints, "fext.rows() != 6 * model.njoints");
+  detail::check(q.cols() == v.cols() && q.cols() == a.cols() && q.cols() == tau.cols() && q.cols() == fext.cols(),
+                "column mismatch");
+  throw_status(brbd_aba_fext(pool.handle(), (int64_t)q.cols(), q.data(), (int64_t)q.outerStride(), v.data(),
+                             (int64_t)v.outerStride(), tau.data(), (int64_t)tau.outerStride(), fext.data(),
+                             (int64_t)fext.outerStride(), const_cast<double*>(a.data()),
+                             (int64_t)a.outerStride(), BRBD_INSTANCE_MAJOR, BRBD_HOST, nullptr));
+}
+
+// Batched computeJointJacobians(q) + getJointJacobian(joint_id, rf, J) (algorithm/jacobian.hxx:175-283):
+// J is (6 * nv) x B, column b = the 6 x nv Jacobian of instance b, column-major; rf as
+// pinocchio::ReferenceFrame (0 WORLD, 1 LOCAL, 2 LOCAL_WORLD_ALIGNED).
+template <class ConfigPool, class JacobianPool>
+void getJointJacobian(ModelPool& pool, const ConfigPool& q, int joint_id, int rf, const JacobianPool& J) {
+  detail::check(pool.size() > 0, "The pool should have at least one element");
+  const ModelDesc& m = pool.getModel(0);
+  detail::check(q.rows() == m.nq, "q.rows() != model.nq");
+  detail::check(J.rows() == 6 * m.nv, "J.rows() != 6 * model.nv");
+  detail::check(q.cols() == J.cols(), "column mismatch");
+  throw_status(brbd_joint_jacobian(pool.handle(), (int64_t)q.cols(), q.data(), (int64_t)q.outerStride(), joint_id, rf,
+                                   const_cast<double*>(J.data()), (int64_t)J.outerStride(), BRBD_INSTANCE_MAJOR,
+                                   BRBD_HOST, nullptr));
+}
+
 }  // namespace brbd
 
 // ------------------------------------------------------------------------------------------------
@@ -135,10 +185,20 @@ inline int joint_type_from_shortname(const std::string& s) {
   static const char* names[] = {"JointModelRX", "JointModelRY", "JointModelRZ", "JointModelPX", "JointModelPY",
                                 "JointModelPZ", "JointModelFreeFlyer", "JointModelSpherical",
                                 "JointModelRevoluteUnaligned", "JointModelPrismaticUnaligned", "JointModelRUBX",
-                                "JointModelRUBY", "JointModelRUBZ"};
+                                "JointModelRUBY", "JointModelRUBZ", "JointModelRevoluteUnboundedUnaligned"};
+  static_assert(sizeof(names) / sizeof(names[0]) == BRBD_JOINT_TYPE_COUNT, "one shortname per brbd_joint_type");
   for (int k = 0; k < BRBD_JOINT_TYPE_COUNT; ++k)
     if (s == names[k]) return k;
   throw std::invalid_argument("joint kind " + s + " is not supported by the brbd engine");
+}
+// axis of the unaligned joint kinds (public member, e.g. joint-revolute-unaligned.hpp:734)
+template <class JointModelKind>
+inline bool axis_of(const pinocchio::JointModel& joint, double* out) {
+  if (const JointModelKind* p = boost::get<JointModelKind>(&joint.toVariant())) {
+    for (int k = 0; k < 3; ++k) out[k] = p->axis[k];
+    return true;
+  }
+  return false;
 }
 inline ModelDesc make_desc(const pinocchio::Model& model) {
   ModelDesc d;
@@ -160,6 +220,10 @@ inline ModelDesc make_desc(const pinocchio::Model& model) {
     d.inertia[10 * (size_t)i] = Y.mass();
     std::memcpy(&d.inertia[10 * (size_t)i + 1], Y.lever().data(), 3 * sizeof(double));
     std::memcpy(&d.inertia[10 * (size_t)i + 4], Y.inertia().data().data(), 6 * sizeof(double));
+    double* ax = &d.axis[3 * (size_t)i];
+    (void)(axis_of<pinocchio::JointModelRevoluteUnaligned>(model.joints[(size_t)i], ax) ||
+           axis_of<pinocchio::JointModelPrismaticUnaligned>(model.joints[(size_t)i], ax) ||
+           axis_of<pinocchio::JointModelRevoluteUnboundedUnaligned>(model.joints[(size_t)i], ax));
   }
   return d;
 }

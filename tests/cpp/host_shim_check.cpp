@@ -49,6 +49,13 @@ int main() {
   fails += !throws_invalid([&] { brbd::abaInParallel(1, pool, q, few, a, tau); });
   fails += !throws_invalid([&] { brbd::abaInParallel(1, pool, q, v, bad, a); });
   fails += !throws_invalid([&] { pool.getModel(7); });
+  // external forces / joint Jacobian wrappers: (6 * njoints) x B and (6 * nv) x B matrices
+  Mat fext(12, 4), fbad(6, 4), J(6, 4), Jbad(5, 4);
+  fails += !throws_invalid([&] { brbd::rnea(pool, q, v, a, fbad, tau); });
+  fails += !throws_invalid([&] { brbd::aba(pool, q, v, tau, fext, few); });
+  fails += !throws_invalid([&] { brbd::getJointJacobian(pool, q, 1, 1, Jbad); });
+  fails += !throws_invalid([&] { brbd::rnea(pool, bad, v, a, fext, tau); });
+  (void)J;
   std::printf("host shim checks: %s\n", fails ? "FAILED" : "ok");
   return fails;
 }

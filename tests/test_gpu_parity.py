@@ -102,6 +102,19 @@ def test_empty_batch():
     pool.release()
 
 
+def test_empty_batch_new_entry_points():
+    model = S.manipulator()
+    pool = parallel.ModelPool(model, 1)
+    z = np.zeros((6, 0))
+    f = np.zeros((6 * model.njoints, 0))
+    assert parallel.rnea(pool, z, z, z, f).shape == (6, 0)
+    assert parallel.aba(pool, z, z, z, f).shape == (6, 0)
+    assert parallel.getJointJacobian(pool, z, 3, capi.WORLD).shape == (36, 0)
+    with pytest.raises(capi.BrbdInvalidArgument):   # fext must have 6 rows per joint, universe included
+        parallel.rnea(pool, np.zeros((6, 4)), np.zeros((6, 4)), np.zeros((6, 4)), np.zeros((6 * (model.njoints - 1), 4)))
+    pool.release()
+
+
 def test_in_place_overloads_and_mixed_orders():
     """pin.rneaInParallel(n, pool, q, v, a, tau) / abaInParallel(..., a) write the caller's array
     (bindings/python/algorithm/parallel/rnea.cpp:44-63)."""

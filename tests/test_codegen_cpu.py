@@ -151,3 +151,32 @@ def test_signature_distinguishes_pattern_and_dense():
     m2 = S.quadruped()
     m2.armature = np.full(m2.nv, 0.1)
     assert joints.ModelView(m2, dense=True).signature() != sd  # armature pattern is always exact
+
+
+def test_built_kernels_have_no_scratch_with_spilled_sgprs():
+    """Register reports of the last build (pinocchio_amd/csrc/gen/*.usage, tools/spec_usage.py): no
+    compiled kernel may combine scratch memory with spilled SGPRs (the combination that miscompiled
+    under hipcc 7.2 during development), and the headline kernels use no scratch."""
+    import glob, os, re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pinocchio_amd", "csrc", "gen")
+    files = glob.glob(os.path.join(root, "*.usage"))
+    if not files:
+        pytest.skip("no build reports in this tree")
+    seen = 0
+    for f in files:
+        cur = None
+        for line in open(f):
+            m = re.search(r"Function Name: (\S+)", line)
+            if m:
+                cur = {"name": m.group(1)}
+                continue
+            m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\S+)", line)
+            if m and cur is not None:
+                cur[m.group(1).strip()] = m.group(2)
+                if m.group(1).strip() == "VGPRs Spill" and "k_" in cur["name"]:
+                    seen += 1
+                    scratch, sgpr = int(cur.get("ScratchSize", 0)), int(cur.get("SGPRs Spill", 0))
+                    assert not (scratch > 0 and sgpr > 8), cur
+                    if "simple_humanoid" in cur["name"] and ("k_rnea" in cur["name"] or "k_aba" in cur["name"]):
+                        assert scratch == 0, cur
+    assert seen > 0

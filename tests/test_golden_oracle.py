@@ -28,6 +28,17 @@ def test_oracle_matches_golden(name):
             assert np.abs(x - y).max() < 1e-12 * max(1.0, np.abs(y).max())
 
 
+@pytest.mark.parametrize("name", NAMES)
+def test_oracle_matches_golden_external_forces_and_joint_jacobians(name):
+    g, e = np.load(os.path.join(GOLD, name + ".npz")), np.load(os.path.join(GOLD, name + "_ext.npz"))
+    O = oracle.Oracle(S.build(name))
+    assert rel_err_cols(O.rnea_fext(g["q"], g["v"], g["a"], e["fext"]), e["tau_fext"]).max() < 1e-13
+    assert rel_err_cols(O.aba_fext(g["q"], g["v"], e["tau_fext"], e["fext"]), e["ddq_fext"]).max() < 1e-11
+    j = int(e["joint"])
+    for rf, key in ((0, "J_world"), (1, "J_local"), (2, "J_lwa")):
+        assert np.abs(O.joint_jacobian(g["q"], j, rf) - e[key]).max() < 1e-13
+
+
 def test_model_tables_are_stable():
     """The committed simple_humanoid table has the dimensions SURVEY section 8 states."""
     m = S.simple_humanoid()

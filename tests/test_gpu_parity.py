@@ -72,6 +72,11 @@ def test_golden_vectors(name):
     assert rel_err_cols(parallel.abaInParallel(1, pool, g["q"], g["v"], g["tau"]), g["ddq"]).max() < TOL_ABA
     J, oMi = parallel.computeJointJacobians(pool, g["q"], want_oMi=True)
     assert np.abs(J - g["J"]).max() < TOL_KIN and np.abs(oMi - g["oMi"]).max() < TOL_KIN
+    e = np.load(os.path.join(GOLD, name + "_ext.npz"))
+    assert rel_err_cols(parallel.rnea(pool, g["q"], g["v"], g["a"], e["fext"]), e["tau_fext"]).max() < TOL_RNEA
+    assert rel_err_cols(parallel.aba(pool, g["q"], g["v"], e["tau_fext"], e["fext"]), e["ddq_fext"]).max() < TOL_ABA
+    for rf, key in ((capi.WORLD, "J_world"), (capi.LOCAL, "J_local"), (capi.LOCAL_WORLD_ALIGNED, "J_lwa")):
+        assert np.abs(parallel.getJointJacobian(pool, g["q"], int(e["joint"]), rf) - e[key]).max() < TOL_KIN
     if "dtau_dq" in g:
         dq, dv, da = parallel.computeRNEADerivatives(pool, g["q"], g["v"], g["a"])
         assert _mat_rel(dq, g["dtau_dq"]) < TOL_DERIV

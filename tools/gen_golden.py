@@ -47,6 +47,24 @@ def main():
             d.update(dtau_dq=dq, dtau_dv=dv, dtau_da=da)
         np.savez_compressed(os.path.join(out, name + ".npz"), **d)
         print(name, {k: x.shape for k, x in d.items()})
+        # external forces and joint Jacobians (<name>_ext.npz).  Accepted only where the two agree with
+        # each other through tau(fext) = tau(0) - sum_i J_i(LOCAL)^T fext_i, and aba inverts rnea.
+        fext = rng.uniform(-2, 2, (6 * m.njoints, B))
+        tau_f = O.rnea_fext(q, v, a, fext)
+        ddq_f = O.aba_fext(q, v, tau_f, fext)
+        acc = tau.copy()
+        for i in range(1, m.njoints):
+            Jl = O.joint_jacobian(q, i, 1)
+            for b in range(B):
+                acc[:, b] -= Jl[:, b].reshape(m.nv, 6) @ fext[6 * i:6 * i + 6, b]
+        assert np.abs(acc - tau_f).max() < 1e-11 * max(1.0, np.abs(tau_f).max()), name
+        assert np.abs(ddq_f - a).max() < 1e-9, name
+        assert np.abs(O.aba_fext(q, v, tau_f, fext, "local") - ddq_f).max() < 1e-9, name
+        jl = m.njoints - 1
+        e = dict(fext=fext, tau_fext=tau_f, ddq_fext=ddq_f, joint=np.array(jl),
+                 J_world=O.joint_jacobian(q, jl, 0), J_local=O.joint_jacobian(q, jl, 1),
+                 J_lwa=O.joint_jacobian(q, jl, 2))
+        np.savez_compressed(os.path.join(out, name + "_ext.npz"), **e)
 
 
 if __name__ == "__main__":

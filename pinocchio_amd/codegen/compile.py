@@ -28,7 +28,7 @@ ALGOS = {"rnea": rnea.generate, "aba": aba.generate, "fkjac": fkjac.generate, "d
 # storage budgets (doubles per lane) of the park planner, per algorithm:
 # (registers for short-lived parks, LDS, registers for long-lived parks)
 # LDS: 160 KiB per CU, 4 resident waves of 64 lanes at one wave per SIMD -> 80 doubles per lane
-BUDGETS = {"rnea": (40, 80, 0), "aba": (16, 80, 100, 64), "fkjac": (36, 80, 0), "deriv": (64, 80, 32, 64)}  # (deriv: first rung of LADDER)
+BUDGETS = {"rnea": (40, 80, 0), "aba": (48, 80, 100, 64), "fkjac": (36, 80, 0), "deriv": (64, 80, 32, 64)}  # (deriv: first rung of LADDER)
 for _a in list(BUDGETS):  # experiment hook: BRBD_CG_ABA="64,80"
     _v = os.environ.get("BRBD_CG_" + _a.upper())
     if _v:
@@ -52,9 +52,10 @@ FINE = set(os.environ.get("BRBD_CG_FINE", "deriv").split(","))
 # parks to fill every class to its limit at once.  ``build_kernel`` walks down the ladder until
 # the body's register-pressure estimate (doubles live in program order) fits: hipcc spills to
 # scratch beyond ~200 doubles (512 registers per lane at one wave per SIMD, minus addressing).
-LADDER = {"deriv": [(64, 80, 32, 64), (40, 80, 32, 64), (24, 80, 16, 64), (8, 80, 0, 64), (0, 80, 0, 64),
+LADDER = {"aba": [(48, 80, 100, 64), (32, 80, 100, 64), (16, 80, 100, 64), (16, 80, 80, 64)],
+          "deriv": [(64, 80, 32, 64), (40, 80, 32, 64), (24, 80, 16, 64), (8, 80, 0, 64), (0, 80, 0, 64),
                     (0, 80, 0, 48), (0, 80, 0, 24)]}
-LIVE_MAX = {"deriv": 182}
+LIVE_MAX = {"aba": 230, "deriv": 182}
 
 _IDENT = re.compile(r"\b([a-z][a-z]?_?[0-9]+(?:_[0-9]+)?|[sc]_t[0-9]+)\b")
 

@@ -2,7 +2,7 @@
 # A/B: run bench.py (no CPU baseline) against each gpurun_out/lib_<tag>.so given; prints kernel times
 cd "${GRAFT_REPO_ROOT:-.}"
 for t in "$@"; do
-  BRBD_LIB=$PWD/ab_libs/lib_$t.so timeout -k 10 120 python bench.py --steps 1000 --warmup 300 --no-cpu-baseline > gpurun_out/ab_$t.json 2> gpurun_out/ab_$t.err || { echo "$t FAILED"; tail -3 gpurun_out/ab_$t.err; continue; }
+  BRBD_LIB=$PWD/ab_libs/lib_$t.so timeout -k 10 120 python bench.py --steps 600 --warmup 300 --no-cpu-baseline > gpurun_out/ab_$t.json 2> gpurun_out/ab_$t.err || { echo "$t FAILED"; tail -3 gpurun_out/ab_$t.err; continue; }
   python - "$t" <<'PY'
 import json,sys
 t=sys.argv[1]; d=json.load(open(f"gpurun_out/ab_{t}.json"))

@@ -43,15 +43,22 @@ struct SpecEntry {
 // is out of range is dropped by the hardware instead of faulting.  The host only selects these
 // kernels when every matrix spans less than 4 GiB (32-bit byte offsets).
 // Lanes past the end of the batch are clamped onto the last instance (same values re-stored).
+// Cache policy of the boundary matrices (aux operand of the buffer instructions; 2 = nt).  Inputs
+// are read once and outputs written once: in BATCH_MAJOR every access is a full 512-byte row
+// segment, and streaming it past the L2 is worth 13 % on the headline (RNEA 18.9 -> 16.4 us, ABA
+// 44.9 -> 40.1 us) and 20 % on the output-bound kernels.  INSTANCE_MAJOR keeps the default policy:
+// its lanes touch one cache line each and live on L2 hits (nt there: 1.08e9 -> 0.43e9 evals/s).
+// The kernel template sets SPEC_IN_AUX / SPEC_OUT_AUX (codegen/build.py: nt loads slow the
+// output-bound derivative and FK + Jacobian kernels down, so they stream only their stores).
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 DI __amdgpu_buffer_rsrc_t spec_rsrc(const void* base, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
 }
-template <int LAYOUT>
+template <int LAYOUT, int AUX>
 struct SpecMat;
-template <>
-struct SpecMat<1> {  // BATCH_MAJOR: element (d, b) at byte d * ld8 + b * 8
+template <int AUX>
+struct SpecMat<1, AUX> {  // BATCH_MAJOR: element (d, b) at byte d * ld8 + b * 8
   __amdgpu_buffer_rsrc_t r;
   unsigned voff;
   DI SpecMat(const double* base, unsigned bytes, unsigned ld8, int64_t b) : r(spec_rsrc(base, bytes)) {
@@ -59,14 +66,14 @@ struct SpecMat<1> {  // BATCH_MAJOR: element (d, b) at byte d * ld8 + b * 8
     voff = (unsigned)b * 8u;
   }
   DI double get(int d, unsigned ld8) const {
-    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, (unsigned)d * ld8, 0));
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, (unsigned)d * ld8, AUX));
   }
   DI void put(int d, unsigned ld8, double x) const {
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, x), r, voff, (unsigned)d * ld8, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, x), r, voff, (unsigned)d * ld8, AUX);
   }
 };
-template <>
-struct SpecMat<0> {  // INSTANCE_MAJOR: element (d, b) at byte b * ld8 + d * 8 (immediate offset)
+template <int AUX>
+struct SpecMat<0, AUX> {  // INSTANCE_MAJOR: element (d, b) at byte b * ld8 + d * 8 (immediate offset)
   __amdgpu_buffer_rsrc_t r;
   unsigned voff;
   DI SpecMat(const double* base, unsigned bytes, unsigned ld8, int64_t b) : r(spec_rsrc(base, bytes)) {
@@ -196,14 +203,14 @@ DI void spec_sincos(double x, double& so, double& co) {
 #define BRBD_SPEC_TILE(LAYOUT)                                                                       \
   int64_t inst = tile * WAVE + lane;                                                                 \
   if (inst >= A.B) inst = A.B - 1;                                                                   \
-  const SpecMat<LAYOUT> mq(A.q, A.nb[0], ldq8, inst);                                                \
-  const SpecMat<LAYOUT> mv(A.v, A.nb[1], ldv8, inst);                                                \
-  const SpecMat<LAYOUT> mx(A.a, A.nb[2], ldx8, inst);                                                \
-  const SpecMat<LAYOUT> mo(A.out, A.nb[3], ldo8, inst);                                              \
-  const SpecMat<LAYOUT> mo2(A.out2, A.nb[4], ldo28, inst);                                           \
-  const SpecMat<LAYOUT> mo3(A.out3, A.nb[5], ldo38, inst);                                           \
-  const SpecMat<LAYOUT> mo4(A.out4, A.nb[6], ldo48, inst);                                           \
-  const SpecMat<LAYOUT> mf(A.fext, A.nb[7], ldf8, inst);                                             \
+  const SpecMat<LAYOUT, SPEC_IN_AUX> mq(A.q, A.nb[0], ldq8, inst);                                                \
+  const SpecMat<LAYOUT, SPEC_IN_AUX> mv(A.v, A.nb[1], ldv8, inst);                                                \
+  const SpecMat<LAYOUT, SPEC_IN_AUX> mx(A.a, A.nb[2], ldx8, inst);                                                \
+  const SpecMat<LAYOUT, SPEC_OUT_AUX> mo(A.out, A.nb[3], ldo8, inst);                                              \
+  const SpecMat<LAYOUT, SPEC_OUT_AUX> mo2(A.out2, A.nb[4], ldo28, inst);                                           \
+  const SpecMat<LAYOUT, SPEC_OUT_AUX> mo3(A.out3, A.nb[5], ldo38, inst);                                           \
+  const SpecMat<LAYOUT, SPEC_OUT_AUX> mo4(A.out4, A.nb[6], ldo48, inst);                                           \
+  const SpecMat<LAYOUT, SPEC_IN_AUX> mf(A.fext, A.nb[7], ldf8, inst);                                             \
   (void)mv; (void)mx; (void)mo; (void)mo2; (void)mo3; (void)mo4; (void)ldo38; (void)ldo48; (void)mf; (void)ldf8;
 
 }  // namespace brbd

@@ -4,7 +4,8 @@ numpy implementation in oracle/naive_np.py.
 
 TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
 cpu_baseline leg.  Nothing under pinocchio_amd/ imports this package.
-PARITY UNPINNED BY VALUE (see oracle/brbd_oracle.h).
+RNEA is pinned by value against the reference's own test vectors (tests/test_reference_values.py);
+ABA / Jacobians / derivatives by the reference's invariants (see oracle/brbd_oracle.h).
 """
 from __future__ import annotations
 

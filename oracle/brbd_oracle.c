@@ -1,6 +1,7 @@
 /*
  * brbd_oracle.c -- scalar C restatement of the reference's hot path.
- * TEST INFRASTRUCTURE ONLY (see brbd_oracle.h).  PARITY UNPINNED BY VALUE.
+ * TEST INFRASTRUCTURE ONLY (see brbd_oracle.h).  RNEA pinned by value against the reference's
+ * unittest/value.cpp vectors (tests/test_reference_values.py); the rest by invariants.
  *
  * Every function cites the reference file:line whose arithmetic it follows.
  * Citations are relative to /root/reference/include/pinocchio/.

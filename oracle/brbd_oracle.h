@@ -7,12 +7,22 @@
  * bench.py's cpu_baseline leg may call this.  The product (libbrbd_hip.so)
  * never links or loads it.
  *
- * PARITY UNPINNED BY VALUE: the reference cannot be compiled or imported in
- * the build container (needs Eigen, Boost, urdfdom) and holds
- * no golden numbers for this path.  This restatement is
- * pinned by (1) the reference's own test invariants re-expressed in
- * tests/test_oracle_invariants.py and (2) agreement <= 1e-12 with the
- * structurally independent numpy implementation in oracle/naive_np.py.
+ * HOW PARITY IS PINNED.  The reference cannot be compiled or imported in the
+ * build container (needs Eigen, Boost, urdfdom), so there is no
+ * oracle/_ref.  This restatement is pinned
+ * (0) BY VALUE for RNEA: the numbers the reference's own tests hold --
+ *     unittest/value.cpp:31-179 (five RNEA vectors on simple_humanoid.urdf +
+ *     free-flyer, the headline model, tolerances 1e-12 .. 1e-6) and
+ *     unittest/joint-prismatic.cpp:137-216 -- committed as
+ *     tests/golden/reference_value_cpp.json, tests/test_reference_values.py;
+ * (1) by the reference's own test invariants re-expressed in
+ *     tests/test_oracle_invariants.py (aba(rnea(a)) = a ties ABA to the
+ *     value-pinned RNEA; derivatives vs finite differences of it; J qdot =
+ *     oMi.act(v)); and
+ * (2) by agreement <= 1e-12 with the structurally independent numpy
+ *     implementation in oracle/naive_np.py.
+ * ABA, the Jacobians and the derivatives have no stored numbers in the
+ * reference: for them parity is pinned through (1) and (2) only.
  */
 #ifndef BRBD_ORACLE_H
 #define BRBD_ORACLE_H

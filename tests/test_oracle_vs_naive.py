@@ -1,7 +1,7 @@
 """Pins the C restatement (oracle/brbd_oracle.c) against the structurally independent numpy
 longdouble implementation (oracle/naive_np.py, Featherstone body-frame [ang;lin] algebra) at
-<= 1e-12 -- the two-implementation pin of SURVEY 8c(2).  PARITY UNPINNED BY VALUE: the reference
-holds no golden numbers for this path and cannot be built offline."""
+<= 1e-12 -- the two-implementation pin of SURVEY 8c(2).  (The value pin against the numbers the
+reference's own tests hold is tests/test_reference_values.py.)"""
 import numpy as np
 import pytest
 

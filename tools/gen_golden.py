@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
 """Generate tests/golden/*.npz: small input/output vectors for the built-in models.
 
-The reference holds no golden numbers for this path and cannot be run offline, so the vectors are
+These are REGRESSION vectors, not the value pin: the reference cannot be run offline, so they are
 captured from the build's own oracle pair: the C restatement (oracle/brbd_oracle.c) is accepted
 only where it agrees with the independent numpy-longdouble implementation (oracle/naive_np.py)
-to <= 1e-12 (RNEA, FK, J) / 1e-10 (ABA).  "Parity unpinned by value" w.r.t. the reference.
+to <= 1e-12 (RNEA, FK, J) / 1e-10 (ABA).  The numbers the reference itself holds for this path
+(unittest/value.cpp, unittest/joint-prismatic.cpp) are a separate fixture,
+tests/golden/reference_value_cpp.json (tools/gen_reference_fixture.py, tests/test_reference_values.py).
 """
 import os
 import sys

@@ -4,11 +4,16 @@ per GPU (BASELINE.json configs[2]; the HIP counterpart of the reference's
 benchmark/timings-parallel.cpp:151-207 which times rneaInParallel / abaInParallel).
 
   python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus 8 --model talos_like --batch 1048576 --algo aba     # BASELINE.json configs[3]
 
-One *step* = one rneaInParallel pass + one abaInParallel pass over the rank's batch, inputs and
-outputs resident in HBM in the engine-native BATCH_MAJOR layout.  One rank per GPU, no collective
-on the data path (instances are independent); ranks only meet in the barriers around the timed
-region.  Rank 0 prints ONE JSON line.
+One *step* = one rneaInParallel pass + one abaInParallel pass over the rank's batch (--algo picks
+one of the two), inputs and outputs resident in HBM in the engine-native BATCH_MAJOR layout.  One
+rank per GPU, no collective on the data path (instances are independent); ranks only meet in the
+barriers around the timed region.  Rank 0 prints ONE JSON line.
+
+Run without a launcher and with --gpus N > 1, this process starts the N ranks itself
+(pinocchio_amd/launch.py: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* like torchrun) BEFORE anything
+touches the GPU and stays GPU-free; under `python -m torch.distributed.run` it is one of the ranks.
 """
 from __future__ import annotations
 
@@ -33,7 +38,9 @@ def parse():
     p.add_argument("--steps", type=int, default=2000)
     p.add_argument("--warmup", type=int, default=300)
     p.add_argument("--batch", type=int, default=65536, help="instances per GPU")
-    p.add_argument("--model", default="simple_humanoid")
+    p.add_argument("--model", default="simple_humanoid",
+                   help="built-in model name, or the path of a URDF file (free-flyer root is added)")
+    p.add_argument("--algo", default="rnea+aba", choices=["rnea+aba", "rnea", "aba"])
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
     return p.parse_args()
@@ -55,7 +62,8 @@ def cpu_baseline(model, q, v, a, seconds):
     import oracle
     O = oracle.Oracle(model)
     threads = oracle.max_threads()
-    qf, vf, af = (np.asfortranarray(x) for x in (q, v, a))
+    n = min(q.shape[1], 65536)   # a bounded sample of the same workload
+    qf, vf, af = (np.asfortranarray(x[:, :n]) for x in (q, v, a))
     B = qf.shape[1]
     tau = O.rnea(qf, vf, af, threads=threads)   # warm-up (thread pool, page faults)
     O.aba(qf, vf, tau, threads=threads)
@@ -74,16 +82,39 @@ def cpu_baseline(model, q, v, a, seconds):
             break
     return {
         "value": 2 * B * passes / (t_r + t_a), "unit": "evals/s", "cores": threads, "kind": "port",
-        "sample": f"{passes} passes of RNEA+ABA over the same {B}-instance batch, OpenMP static schedule",
+        "sample": f"{passes} passes of RNEA+ABA over the first {B} instances of the same batch, OpenMP static schedule",
         "rnea_evals_per_s": B * passes / t_r, "aba_evals_per_s": B * passes / t_a,
     }
 
 
+def load_model(spec):
+    from pinocchio_amd import sample_models, urdf
+    if spec.endswith(".urdf") or os.sep in spec:
+        with open(spec) as f:
+            return urdf.build_model_from_urdf(f.read(), free_flyer=True, name=os.path.splitext(os.path.basename(spec))[0])
+    return sample_models.build(spec)
+
+
+def counted_flops(name):
+    """Algorithmic flops per eval, counted with a counting scalar over the reference-structured
+    restatement and frozen in BASELINE.md section 3 (tools/flops/count_flops.py)."""
+    frozen = {"simple_humanoid": {"rnea": 10278, "aba": 27374}, "talos_like": {"rnea": 11295, "aba": 29936},
+              "quadruped": {"rnea": 4515, "aba": 12856}, "arm7": {"rnea": 2277, "aba": 5633},
+              "manipulator": {"rnea": 1938, "aba": 4779}, "baxter_simple": {"rnea": 6105, "aba": 15143}}
+    return frozen.get(name[:-3] if name.endswith("_ff") else name)
+
+
 def main():
     args = parse()
+    from pinocchio_amd import launch
+    if args.gpus > 1 and not launch.under_launcher():
+        # one process per GPU, started before any GPU call; this parent never touches the device
+        raise SystemExit(launch.spawn_ranks(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if os.environ.get("BRBD_BENCH_ECHO_RANK"):
+        print(f"bench rank {rank}/{world}", file=sys.stderr, flush=True)
     import torch
     from pinocchio_amd import capi, parallel, sample_models
 
@@ -96,7 +127,8 @@ def main():
         dist = dist_
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    model = sample_models.build(args.model)
+    model = load_model(args.model)
+    do_rnea, do_aba = "rnea" in args.algo, "aba" in args.algo
     B = args.batch
     pool = parallel.ModelPool(model, 1)
     qh, vh, ah = make_inputs(model, B, rank)
@@ -106,9 +138,15 @@ def main():
     ddq = torch.empty((model.nv, B), dtype=torch.float64, device=dev)
     dm = pool.device_model(local_rank)
 
-    def step():
+    if not do_rnea:  # ABA alone: its torques come from one untimed RNEA pass
         parallel.rneaInParallel(1, pool, q, v, a, tau)
-        parallel.abaInParallel(1, pool, q, v, tau, ddq)
+    evals_per_step = B * (int(do_rnea) + int(do_aba))
+
+    def step():
+        if do_rnea:
+            parallel.rneaInParallel(1, pool, q, v, a, tau)
+        if do_aba:
+            parallel.abaInParallel(1, pool, q, v, tau, ddq)
 
     def fence():
         torch.cuda.synchronize()
@@ -144,55 +182,117 @@ def main():
         elapsed = float(t.item())
     n_r, ms_r = dm.kernel_time(capi.ALGO_RNEA)
     n_a, ms_a = dm.kernel_time(capi.ALGO_ABA)
+    if not do_rnea:
+        n_r, ms_r = 0, 0.0
 
     # parity spot check of the timed outputs: ABA(RNEA(a)) == a (reference unittest/aba.cpp:143-154)
-    err = float(((ddq - a).norm(dim=0) / a.norm(dim=0)).max().item())
+    err = float(((ddq - a).norm(dim=0) / a.norm(dim=0)).max().item()) if do_aba else None
 
-    # the same step with the reference's own instance-major (Eigen column-major) layout, untimed
-    # region of its own: reported in config, never in `value`
+    def timed_steps(fn, k):
+        # (fresh buffers and kernels: the first few dozen launches run slower -- first-touch page
+        # mappings, code-object load -- so warm up like the main region does)
+        for _ in range(max(args.warmup // 3, 20)):
+            fn()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(k):
+            fn()
+        torch.cuda.synchronize()
+        return evals_per_step * k / (time.perf_counter() - t)
+
+    # Side figures, each in a region of its own, reported in `config`, never in `value`:
+    k_side = max(args.steps // 4, 5)
+    # (1) the same step in the reference's own instance-major (Eigen column-major) layout, device-resident
     qi, vi, ai = (x.t().contiguous().t() for x in (q, v, a))
-    taui = torch.empty((B, model.nv), dtype=torch.float64, device=dev).t()
+    taui = tau.t().contiguous().t()
     ddqi = torch.empty((B, model.nv), dtype=torch.float64, device=dev).t()
-    for _ in range(3):
-        parallel.rneaInParallel(1, pool, qi, vi, ai, taui)
-        parallel.abaInParallel(1, pool, qi, vi, taui, ddqi)
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    k_im = max(args.steps // 4, 5)
-    for _ in range(k_im):
-        parallel.rneaInParallel(1, pool, qi, vi, ai, taui)
-        parallel.abaInParallel(1, pool, qi, vi, taui, ddqi)
-    torch.cuda.synchronize()
-    im_rate = 2 * B * k_im / (time.perf_counter() - t1)
+
+    def step_im():
+        if do_rnea:
+            parallel.rneaInParallel(1, pool, qi, vi, ai, taui)
+        if do_aba:
+            parallel.abaInParallel(1, pool, qi, vi, taui, ddqi)
+    im_rate = timed_steps(step_im, k_side)
+    # (2) the table-driven kernels (what a model unknown at build time runs on)
+    variant = dm.compiled_kernels()
+    td_rate = None
+    if variant:
+        dm.use_compiled(False)
+        td_rate = timed_steps(step, max(k_side // 4, 3))
+        dm.use_compiled(True)
+    # (3) end to end from HOST memory in the reference's calling convention (Eigen column-major
+    # matrices in, results back in host memory; PCIe-inclusive, SURVEY 8d "timing hygiene")
+    host_rate = host_pinned_rate = None
+    if rank == 0:
+        def host_steps(qf, vf, af, tauf, outf):
+            def step_host():
+                if do_rnea:
+                    parallel.rneaInParallel(1, pool, qf, vf, af, tauf)
+                if do_aba:
+                    parallel.abaInParallel(1, pool, qf, vf, tauf, outf)
+            step_host()
+            t1 = time.perf_counter()
+            k_h = 0
+            while k_h < 5 or (time.perf_counter() - t1 < 0.5 and k_h < 50):
+                step_host()
+                k_h += 1
+            return evals_per_step * k_h / (time.perf_counter() - t1)
+
+        tau_h = tau.cpu().numpy()
+        # pageable memory (plain Eigen / numpy matrices): the copies block the host
+        host_rate = host_steps(*(np.asfortranarray(x) for x in (qh, vh, ah, tau_h)), np.empty((model.nv, B), order="F"))
+        # page-locked memory (hipHostMalloc / brbd_host_register): DMA copies, upload | kernels | download overlap
+        def pinned(x):
+            t = torch.empty((x.shape[1], x.shape[0]), dtype=torch.float64).pin_memory()
+            t.copy_(torch.from_numpy(np.ascontiguousarray(x.T)))
+            return t.numpy().T  # (dof, B) Fortran-ordered view of the pinned buffer
+        host_pinned_rate = host_steps(pinned(qh), pinned(vh), pinned(ah), pinned(tau_h), pinned(np.zeros((model.nv, B))))
 
     if rank == 0:
         bytes_per_eval = (model.nq + 3 * model.nv) * 8   # q + v + a/tau in, tau/ddq out
         avg_r = ms_r / max(n_r, 1)
         avg_a = ms_a / max(n_a, 1)
-        # dominant kernel = ABA
-        ach = bytes_per_eval * B / (avg_a * 1e-3) / 1e9 if avg_a > 0 else 0.0
-        traffic = None
+        pm = {}
         tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tj):
+        if os.path.exists(tj) and args.model == "simple_humanoid" and B == 65536:
             try:
                 with open(tj) as f:
-                    traffic = json.load(f).get("aba_kernel_bytes_per_launch")
+                    pm = json.load(f)
             except Exception:
-                traffic = None
-        # algorithmic flops per eval (SURVEY 8d pre-estimates); what the kernels execute is in
-        # profiles/pmc_traffic.json (PMC: SQ_INSTS_VALU_{FMA,ADD,MUL}_F64, FMA = 2)
-        flops = {"rnea": 8.5e3, "aba": 18.5e3}
-        executed = None
-        try:
-            with open(tj) as f:
-                executed = json.load(f).get("executed_flops_per_eval")
-        except Exception:
-            executed = None
-        variant = dm.compiled_kernels()
-        kname = (f"brbd::spec_{variant}::k_aba<1, 1>" if variant else "brbd::aba_kernel<1>")
+                pm = {}
+        flops = counted_flops(model.name)
+        executed = pm.get("executed_flops_per_eval") or {}
+        # dominant kernel: ABA when it runs (fp64-issue bound), else RNEA (HBM bound)
+        dom = "aba" if do_aba else "rnea"
+        avg = avg_a if do_aba else avg_r
+        kname = (f"brbd::spec_{variant}::k_{dom}<1, 1>" if variant else f"brbd::{dom}_kernel<1>")
+        gbs = bytes_per_eval * B / (avg * 1e-3) / 1e9 if avg > 0 else 0.0
+        traffic = pm.get(f"{dom}_kernel_bytes_per_launch")
+        if dom == "aba" and flops:
+            tf = flops["aba"] * B / (avg * 1e-3) / 1e12 if avg > 0 else 0.0
+            roof = {"bound": "fp64", "kernel": kname, "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": tf / FP64_PEAK_TFLOPS,
+                    "algorithmic_flops_per_launch": flops["aba"] * B,
+                    "algorithmic_flops_per_eval": flops,
+                    "flops_source": "counted with a counting scalar over the reference-structured restatement "
+                                    "(BASELINE.md section 3, profiles/counted_flops.json)",
+                    "executed_flops_per_eval": executed or None,
+                    "frac_executed": (executed["aba"] * B / (avg * 1e-3) / 1e12 / FP64_PEAK_TFLOPS) if executed.get("aba") else None,
+                    "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                            "algorithmic_bytes_per_launch": bytes_per_eval * B},
+                    "traffic": traffic,
+                    "traffic_source": "static: profiles/pmc_traffic.json (rocprofv3 --pmc passes of this workload, "
+                                      "tools/pmc_passes.sh), not measured in this run" if traffic else None}
+        else:
+            roof = {"bound": "hbm", "kernel": kname, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": bytes_per_eval * B,
+                    "traffic": traffic,
+                    "traffic_source": "static: profiles/pmc_traffic.json, not measured in this run" if traffic else None}
+        headline = args.model == "simple_humanoid" and B == 65536 and args.algo == "rnea+aba"
         out = {
-            "metric": "ABA/RNEA evals/sec, humanoid fp64 batch 65536",
-            "value": 2 * B * args.steps * world / elapsed,
+            "metric": ("ABA/RNEA evals/sec, humanoid fp64 batch 65536" if headline
+                       else f"{args.algo} evals/sec, {model.name} fp64 batch {B} per GPU"),
+            "value": evals_per_step * args.steps * world / elapsed,
             "unit": "evals/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -204,32 +304,32 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.model} (free-flyer, nq {model.nq} / nv {model.nv}) RNEA + ABA, "
+                "workload": f"{model.name} (nq {model.nq} / nv {model.nv}) {args.algo.upper().replace('+', ' + ')}, "
                             f"batch {B} per GPU, fp64, device-resident BATCH_MAJOR",
                 "batch_per_gpu": B,
-                "evals_per_step_per_gpu": 2 * B,
-                "rnea_kernel_ms": avg_r, "aba_kernel_ms": avg_a,
+                "evals_per_step_per_gpu": evals_per_step,
+                "rnea_kernel_ms": avg_r if do_rnea else None, "aba_kernel_ms": avg_a if do_aba else None,
                 "rnea_evals_per_s_kernel": B / (avg_r * 1e-3) if avg_r > 0 else None,
                 "aba_evals_per_s_kernel": B / (avg_a * 1e-3) if avg_a > 0 else None,
                 "instance_major_evals_per_s": im_rate,
+                "table_driven_evals_per_s": td_rate,
+                "host_instance_major_evals_per_s": host_rate,
+                "host_pinned_instance_major_evals_per_s": host_pinned_rate,
                 "max_rel_err_aba_of_rnea": err,
                 "kernels": (f"model-compiled ({variant})" if variant else "table-driven"),
                 "parallelism": f"dp{world} (independent slices, no collective)",
             },
-            "roofline": {
-                "bound": "hbm", "kernel": kname, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                "algorithmic_bytes_per_launch": bytes_per_eval * B,
-            },
-            "roofline_fp64": {
-                "kernel": kname, "achieved": flops["aba"] * B / (avg_a * 1e-3) / 1e12 if avg_a > 0 else None,
-                "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": (flops["aba"] * B / (avg_a * 1e-3) / 1e12 / FP64_PEAK_TFLOPS) if avg_a > 0 else None,
-                "rnea_achieved": flops["rnea"] * B / (avg_r * 1e-3) / 1e12 if avg_r > 0 else None,
-                "algorithmic_flops_per_eval": flops,
-                "executed_flops_per_eval": executed,
-            },
+            "roofline": roof,
         }
+        if do_rnea and do_aba:
+            gr = bytes_per_eval * B / (avg_r * 1e-3) / 1e9 if avg_r > 0 else 0.0
+            out["roofline_rnea"] = {
+                "bound": "hbm", "kernel": kname.replace("k_aba", "k_rnea").replace("aba_kernel", "rnea_kernel"),
+                "achieved": gr, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gr / HBM_PEAK_GBS,
+                "traffic": pm.get("rnea_kernel_bytes_per_launch"),
+                "fp64_frac_counted": (flops["rnea"] * B / (avg_r * 1e-3) / 1e12 / FP64_PEAK_TFLOPS) if flops and avg_r > 0 else None,
+                "fp64_frac_executed": (executed["rnea"] * B / (avg_r * 1e-3) / 1e12 / FP64_PEAK_TFLOPS) if executed.get("rnea") and avg_r > 0 else None,
+            }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, qh, vh, ah, args.cpu_seconds)
         print(json.dumps(out), flush=True)

@@ -136,7 +136,11 @@ enum brbd_algo { BRBD_ALGO_RNEA = 0, BRBD_ALGO_ABA = 1, BRBD_ALGO_FK_JAC = 2, BR
  * = impl::rnea (algorithm/rnea.hxx:117-161).
  * `stream` is a hipStream_t (NULL = default stream).  With BRBD_DEVICE the call
  * is asynchronous on `stream`; with BRBD_HOST it returns after the results are
- * in `tau`. */
+ * in `tau` (the batch is pipelined in column chunks over two internal streams
+ * ordered after `stream`; caller padding, ld > rows, is neither read nor written).
+ * Re-entrancy: workspace and staging are kept per (handle, stream), so calls on
+ * different streams of one handle may overlap; one stream of one handle must be
+ * driven by one host thread at a time. */
 int brbd_rnea(brbd_model* m, int64_t B, const double* q, int64_t ldq, const double* v, int64_t ldv,
               const double* a, int64_t lda, double* tau, int64_t ldtau, int layout, int memspace,
               void* stream);
@@ -161,6 +165,13 @@ int brbd_rnea_fext(brbd_model* m, int64_t B, const double* q, int64_t ldq, const
 int brbd_aba_fext(brbd_model* m, int64_t B, const double* q, int64_t ldq, const double* v, int64_t ldv,
                   const double* tau, int64_t ldtau, const double* fext, int64_t ldfext, double* ddq,
                   int64_t ldddq, int layout, int memspace, void* stream);
+
+/* Page-lock / release a host range (hipHostRegister / hipHostUnregister) so that BRBD_HOST calls on
+ * matrices inside it copy by DMA and overlap upload, kernels and download; the caller must
+ * unregister before freeing the memory.  Optional: pageable memory works, only slower.  No
+ * reference counterpart (the reference never leaves host memory). */
+int brbd_host_register(void* ptr, size_t bytes);
+int brbd_host_unregister(void* ptr);
 
 /* forwardKinematics(q) + computeJointJacobians(q) for B instances
  * (algorithm/kinematics.hxx:52-97, algorithm/jacobian.hxx:38-95).
@@ -224,6 +235,14 @@ int brbd_model_use_compiled(brbd_model* m, int enabled);
  * HBM traffic (41% of the stores for a quadruped).  Honoured by the model-compiled kernels; the
  * table-driven kernel writes every element in both modes (same result). */
 int brbd_model_outputs_prezeroed(brbd_model* m, int enabled);
+
+/* Checking build only (pinocchio_amd/libbrbd_hip_check.so, `make -C pinocchio_amd/csrc check`): the
+ * model-compiled kernels address memory through range-checked buffer resources, and the hardware
+ * silently DROPS an out-of-range access; the checking build compares every offset with its range
+ * first and counts violations.  Returns that count after synchronising the device (0 = every
+ * access of every launch on this handle was in range), or -1 in the regular build.  No reference
+ * counterpart. */
+int64_t brbd_debug_oob_count(brbd_model* m);
 
 /* Kernel timing for the roofline (bench.py): with timing enabled every kernel launch of the
  * engine is bracketed by hipEvents recorded on the launch stream.  brbd_kernel_time() waits for

@@ -229,4 +229,79 @@ inline ModelDesc make_desc(const pinocchio::Model& model) {
 }
 }  // namespace brbd
 #endif
+
+// ------------------------------------------------------------------------------------------------
+// Drop-in overloads on Pinocchio's OWN pool type (multibody/pool/model.hpp:19-165): a caller keeps
+//     pinocchio::ModelPool pool(model, n);  brbd::rneaInParallel(n, pool, q, v, a, tau);
+// and only the namespace of the call changes.  The flattened BatchModel lives in a per-pool device
+// cache keyed by the pool's address (SURVEY 8b "Ownership"); Pinocchio has no change notification,
+// so every call re-flattens pool.getModel(0) (a few KB of tables) and rebuilds the device model
+// when any table differs; brbd::forget(pool) drops the entry (call it before the pool dies).
+// NOT COMPILED in the build container (Pinocchio, Eigen and Boost are absent there): written
+// against the reference's headers, exercised only where they exist.
+#if __has_include(<pinocchio/multibody/pool/model.hpp>)
+#include <map>
+#include <memory>
+#include <mutex>
+#include <pinocchio/multibody/pool/model.hpp>
+namespace brbd {
+namespace detail {
+struct PoolEntry {
+  ModelDesc desc;
+  std::unique_ptr<ModelPool> pool;
+};
+inline bool same_tables(const ModelDesc& a, const ModelDesc& b) {
+  return a.njoints == b.njoints && a.nq == b.nq && a.nv == b.nv && a.parents == b.parents && a.jtype == b.jtype &&
+         a.idx_q == b.idx_q && a.idx_v == b.idx_v && a.placement == b.placement && a.inertia == b.inertia &&
+         a.axis == b.axis && a.armature == b.armature && a.gravity[0] == b.gravity[0] &&
+         a.gravity[1] == b.gravity[1] && a.gravity[2] == b.gravity[2];
+}
+inline std::map<const void*, PoolEntry>& pool_cache() {
+  static std::map<const void*, PoolEntry> c;
+  return c;
+}
+inline std::mutex& pool_cache_mutex() {
+  static std::mutex m;
+  return m;
+}
+template <class PinPool>
+inline ModelPool& device_pool(PinPool& pool) {
+  PINOCCHIO_CHECK_INPUT_ARGUMENT(pool.size() > 0, "The pool should have at least one element");
+  ModelDesc now = make_desc(pool.getModel(0));
+  std::lock_guard<std::mutex> g(pool_cache_mutex());
+  PoolEntry& e = pool_cache()[static_cast<const void*>(&pool)];
+  if (!e.pool || !same_tables(e.desc, now)) {  // first use, or the model was changed / pool.update() called
+    e.desc = now;
+    e.pool.reset(new ModelPool(e.desc, (size_t)pool.size()));
+  }
+  e.pool->resize((size_t)pool.size());
+  return *e.pool;
+}
+}  // namespace detail
+
+template <typename Scalar, int Options, template <typename, int> class JointCollectionTpl>
+inline void forget(const pinocchio::ModelPoolTpl<Scalar, Options, JointCollectionTpl>& pool) {
+  std::lock_guard<std::mutex> g(detail::pool_cache_mutex());
+  detail::pool_cache().erase(static_cast<const void*>(&pool));
+}
+
+// same template header as algorithm/parallel/rnea.hpp:31-45, for Scalar = double
+template <int Options, template <typename, int> class JointCollectionTpl, typename ConfigVectorPool,
+          typename TangentVectorPool1, typename TangentVectorPool2, typename TangentVectorPool3>
+void rneaInParallel(const size_t num_threads, pinocchio::ModelPoolTpl<double, Options, JointCollectionTpl>& pool,
+                    const Eigen::MatrixBase<ConfigVectorPool>& q, const Eigen::MatrixBase<TangentVectorPool1>& v,
+                    const Eigen::MatrixBase<TangentVectorPool2>& a, const Eigen::MatrixBase<TangentVectorPool3>& tau) {
+  rneaInParallel(num_threads, detail::device_pool(pool), q.derived(), v.derived(), a.derived(),
+                 tau.const_cast_derived());
+}
+template <int Options, template <typename, int> class JointCollectionTpl, typename ConfigVectorPool,
+          typename TangentVectorPool1, typename TangentVectorPool2, typename TangentVectorPool3>
+void abaInParallel(const size_t num_threads, pinocchio::ModelPoolTpl<double, Options, JointCollectionTpl>& pool,
+                   const Eigen::MatrixBase<ConfigVectorPool>& q, const Eigen::MatrixBase<TangentVectorPool1>& v,
+                   const Eigen::MatrixBase<TangentVectorPool2>& tau, const Eigen::MatrixBase<TangentVectorPool3>& a) {
+  abaInParallel(num_threads, detail::device_pool(pool), q.derived(), v.derived(), tau.derived(),
+                a.const_cast_derived());
+}
+}  // namespace brbd
+#endif
 #endif

@@ -30,13 +30,14 @@ ALGO_RNEA, ALGO_ABA, ALGO_FK_JAC, ALGO_RNEA_DERIV = 0, 1, 2, 3
 # pinocchio::ReferenceFrame (multibody/fwd.hpp:46-54)
 WORLD, LOCAL, LOCAL_WORLD_ALIGNED = 0, 1, 2
 
-# every extern "C" symbol of include/brbd.h (checked by tests/test_capi_symbols.py)
+# every extern "C" symbol of include/brbd.h (checked by tests/test_capi_host.py)
 SYMBOLS = (
     "brbd_last_error", "brbd_version", "brbd_device_count",
     "brbd_model_create", "brbd_model_destroy", "brbd_model_dims", "brbd_workspace_bytes",
     "brbd_rnea", "brbd_aba", "brbd_rnea_fext", "brbd_aba_fext", "brbd_fk_jacobians", "brbd_joint_jacobian", "brbd_rnea_derivatives",
     "brbd_transpose_to_batch_major", "brbd_transpose_to_instance_major",
     "brbd_set_timing", "brbd_kernel_time", "brbd_model_compiled_kernels", "brbd_model_use_compiled", "brbd_model_outputs_prezeroed", "brbd_model_canonical_form",
+    "brbd_host_register", "brbd_host_unregister", "brbd_debug_oob_count",
 )
 
 
@@ -121,6 +122,12 @@ def lib():
     L.brbd_rnea.argtypes = [vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, ci, ci, vp]
     L.brbd_aba.restype = ci
     L.brbd_aba.argtypes = [vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, ci, ci, vp]
+    L.brbd_debug_oob_count.restype = i64
+    L.brbd_debug_oob_count.argtypes = [vp]
+    L.brbd_host_register.restype = ci
+    L.brbd_host_register.argtypes = [vp, ctypes.c_size_t]
+    L.brbd_host_unregister.restype = ci
+    L.brbd_host_unregister.argtypes = [vp]
     L.brbd_rnea_fext.restype = ci
     L.brbd_rnea_fext.argtypes = [vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, ci, ci, vp]
     L.brbd_aba_fext.restype = ci

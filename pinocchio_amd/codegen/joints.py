@@ -77,8 +77,10 @@ class ModelView:
 
     def signature(self) -> str:
         """What a model must share with the one this kernel was generated for: the tree, the joint
-        kinds and (unless dense) which constants are exactly 0 / +1 / -1."""
-        head = "n%d;p%s;j%s;" % (self.n, ",".join(map(str, self.parents[1:])), ",".join(map(str, self.jtype[1:])))
+        kinds, the rows of q / v each joint owns (the bodies hard-code them) and (unless dense)
+        which constants are exactly 0 / +1 / -1."""
+        head = "n%d;p%s;j%s;q%s;v%s;" % (self.n, ",".join(map(str, self.parents[1:])), ",".join(map(str, self.jtype[1:])),
+                                         ",".join(map(str, self.idx_q[1:])), ",".join(map(str, self.idx_v[1:])))
         pat = []
         for ident in all_const_idents(self):
             x = self.value(ident)

@@ -37,8 +37,10 @@ int fail(int code, const std::string& msg) {
 #define HIP_TRY(expr)                                                                       \
   do {                                                                                      \
     hipError_t e_ = (expr);                                                                 \
-    if (e_ != hipSuccess)                                                                   \
+    if (e_ != hipSuccess) {                                                                 \
+      (void)hipGetLastError(); /* reported here: do not leave it for an unrelated later call */ \
       return fail(BRBD_ERR_RUNTIME, std::string(#expr) + ": " + hipGetErrorString(e_));     \
+    }                                                                                       \
   } while (0)
 
 struct Ev {  // a hipEvent shared by the launches it delimits
@@ -51,6 +53,20 @@ struct TimedLaunch {
 
 }  // namespace
 
+// Everything a call needs beyond its arguments, per (handle, stream): the kernels' workspace, the
+// device staging of the host-memspace path and the two internal streams its pipeline runs on.
+// Calls on different streams of one handle never share any of it (SURVEY 8b "Threading": the C
+// ABI is re-entrant per handle + stream); two host threads must not drive the SAME stream of the
+// same handle at once, as with HIP itself.
+struct StreamCtx {
+  double* d_ws = nullptr;
+  size_t ws_doubles = 0;
+  double* d_stage = nullptr;  // host-memspace path: two chunk slots of device staging
+  size_t stage_doubles = 0;
+  hipStream_t pipe[2] = {nullptr, nullptr};  // internal streams of the host-memspace pipeline
+  hipEvent_t ev_in = nullptr, ev_done[2] = {nullptr, nullptr};
+};
+
 struct brbd_model {
   FlatModel flat;
   int device = 0;
@@ -59,11 +75,8 @@ struct brbd_model {
   Op* d_prog = nullptr;
   Op* d_prog3 = nullptr;
   int* d_nvsub = nullptr;
-  double* d_ws = nullptr;
-  size_t ws_doubles = 0;
-  // host-memspace staging
-  double* d_stage = nullptr;
-  size_t stage_doubles = 0;
+  std::map<hipStream_t, std::unique_ptr<StreamCtx>> ctxs;
+  unsigned long long* d_oob = nullptr;  // checking build: out-of-range access counter of the compiled kernels
   // per-algorithm launch geometry (waves resident on the device)
   int max_waves[4] = {0, 0, 0, 0};
   int max_waves_spec[4] = {0, 0, 0, 0};
@@ -75,6 +88,7 @@ struct brbd_model {
   bool prezeroed = false;  // brbd_model_outputs_prezeroed: derivative kernels skip structural zeros
   bool use_spec = true;  // BRBD_DISABLE_COMPILED=1 or brbd_model_use_compiled(m, 0): table-driven kernels
   bool use_lds = true;
+  bool warned_4g = false;
   int timing = 0;  // 0 off, 1 two events per launch, 2 chained (one event per launch)
   std::shared_ptr<Ev> last_stop;
   hipStream_t last_stream = nullptr;
@@ -95,7 +109,10 @@ double model_constant(const FlatModel& F, int joint, int field, int index) {
     case SF_M: return jc.m;
     case SF_C: return jc.c[index];
     case SF_I: return jc.I[index];
-    case SF_ARM: return jc.arm[index - jc.idx_v];
+    case SF_ARM: {  // the generator names an armature entry by its dof index; idx_v is part of the
+      const int k = index - jc.idx_v;  // signature, so k is in range for a matched model -- checked anyway
+      return (k >= 0 && k < jc.nvj) ? jc.arm[k] : 0.0;
+    }
     case SF_AXIS: return jc.axis[index];
     default: return F.gravity[index];
   }
@@ -105,6 +122,11 @@ std::string model_signature(const FlatModel& F, bool dense) {
   for (int i = 1; i < F.njoints; ++i) s += (i > 1 ? "," : "") + std::to_string(F.tab_desc[i].parent);
   s += ";j";
   for (int i = 1; i < F.njoints; ++i) s += (i > 1 ? "," : "") + std::to_string(F.tab_desc[i].jtype);
+  // the generated bodies hard-code the rows of q / v / tau each joint reads and writes
+  s += ";q";
+  for (int i = 1; i < F.njoints; ++i) s += (i > 1 ? "," : "") + std::to_string(F.tab_desc[i].idx_q);
+  s += ";v";
+  for (int i = 1; i < F.njoints; ++i) s += (i > 1 ? "," : "") + std::to_string(F.tab_desc[i].idx_v);
   s += ";";
   auto put = [&](double x, bool keep) {
     char c = x == 0.0 ? '0' : (x == 1.0 ? '1' : (x == -1.0 ? 'm' : 'g'));
@@ -130,24 +152,37 @@ std::vector<double> pack_constants(const FlatModel& F, const SpecKernel& k) {
   return ct;
 }
 
-int ensure_ws(brbd_model* m, size_t doubles) {
-  if (doubles <= m->ws_doubles) return BRBD_OK;
-  if (m->d_ws) HIP_TRY(hipFree(m->d_ws));
-  m->d_ws = nullptr;
-  m->ws_doubles = 0;
-  HIP_TRY(hipMalloc(&m->d_ws, doubles * sizeof(double)));
-  m->ws_doubles = doubles;
+// The context of (handle, stream); created on first use.
+StreamCtx* get_ctx(brbd_model* m, hipStream_t s) {
+  std::lock_guard<std::mutex> g(m->mu);
+  std::unique_ptr<StreamCtx>& c = m->ctxs[s];
+  if (!c) c.reset(new StreamCtx());
+  return c.get();
+}
+
+// Grow a per-stream device buffer.  Work already queued on `s` may still use the old one: wait for
+// THAT stream (not the device) before freeing it.  Never reached once the buffer is warm.
+int ensure_buf(double** buf, size_t* have, size_t doubles, hipStream_t s) {
+  if (doubles <= *have) return BRBD_OK;
+  if (*buf) {
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipFree(*buf));
+  }
+  *buf = nullptr;
+  *have = 0;
+  HIP_TRY(hipMalloc(buf, doubles * sizeof(double)));
+  *have = doubles;
   return BRBD_OK;
 }
 
-int ensure_stage(brbd_model* m, size_t doubles) {
-  if (doubles <= m->stage_doubles) return BRBD_OK;
-  if (m->d_stage) HIP_TRY(hipFree(m->d_stage));
-  m->d_stage = nullptr;
-  m->stage_doubles = 0;
-  HIP_TRY(hipMalloc(&m->d_stage, doubles * sizeof(double)));
-  m->stage_doubles = doubles;
-  return BRBD_OK;
+void free_ctx(StreamCtx& c) {
+  if (c.d_ws) (void)hipFree(c.d_ws);
+  if (c.d_stage) (void)hipFree(c.d_stage);
+  for (int k = 0; k < 2; ++k) {
+    if (c.ev_done[k]) (void)hipEventDestroy(c.ev_done[k]);
+    if (c.pipe[k]) (void)hipStreamDestroy(c.pipe[k]);
+  }
+  if (c.ev_in) (void)hipEventDestroy(c.ev_in);
 }
 
 template <typename K>
@@ -180,8 +215,11 @@ int check_common(brbd_model* m, int64_t B, int layout, int memspace) {
   return BRBD_OK;
 }
 
-size_t mat_span(int64_t ld, int64_t dof, int64_t B, int layout) {
-  return (size_t)(layout == BRBD_BATCH_MAJOR ? ld * dof : ld * B);
+// Doubles a dof x B matrix really spans: the last row / column is not padded out to ld.
+double mat_span_bytes(int64_t ld, int64_t dof, int64_t B, int layout) {
+  const double outer = layout == BRBD_BATCH_MAJOR ? (double)dof : (double)B;
+  const double inner = layout == BRBD_BATCH_MAJOR ? (double)B : (double)dof;
+  return outer < 1 ? 0.0 : 8.0 * ((outer - 1) * (double)ld + inner);
 }
 
 void fill_common(const brbd_model* m, KArgs& A, int64_t B) {
@@ -201,6 +239,7 @@ void fill_common(const brbd_model* m, KArgs& A, int64_t B) {
   A.gx = F.gravity[0];
   A.gy = F.gravity[1];
   A.gz = F.gravity[2];
+  A.oob = m->d_oob;
 }
 
 struct Timer {
@@ -210,7 +249,7 @@ struct Timer {
   TimedLaunch t{};
   bool on = false;
   int begin() {
-    if (!m->timing) return BRBD_OK;
+    if (!m->timing || algo < 0) return BRBD_OK;
     // chained timing (brbd_set_timing(m, 2)): the event that closed the previous launch of this
     // handle on this stream opens this one: one event per launch instead of two
     if (m->timing == 2 && m->last_stop && m->last_stream == s) {
@@ -236,8 +275,15 @@ struct Timer {
   }
 };
 
+// Caller-provided workspace (brbd_aba_noalloc): table-driven kernels only, nothing allocated,
+// no timing events; the grid is capped to what the workspace holds.
+struct FixedWs {
+  double* ptr = nullptr;
+  size_t doubles = 0;
+};
+
 // One algorithm launch on device pointers.
-int launch_algo(brbd_model* m, int algo, KArgs& A, int layout, hipStream_t stream) {
+int launch_algo(brbd_model* m, int algo, KArgs& A, int layout, hipStream_t stream, const FixedWs* fixed = nullptr) {
   const FlatModel& F = m->flat;
   if (A.B == 0) return BRBD_OK;
   int per_lane = 0;
@@ -249,8 +295,8 @@ int launch_algo(brbd_model* m, int algo, KArgs& A, int layout, hipStream_t strea
     default: return fail(BRBD_ERR_INVALID_ARGUMENT, "unknown algorithm");
   }
   // model-compiled kernel?  (BATCH_MAJOR addresses elements with 32-bit byte offsets)
-  const SpecKernel* sk = (m->spec && m->use_spec) ? &m->spec->algo[algo] : nullptr;
-  int variant = 0;
+  const SpecKernel* sk = (m->spec && m->use_spec && !fixed) ? &m->spec->algo[algo] : nullptr;
+  int variant = 0, klayout = layout;
   if (sk) {
     if (algo == BRBD_ALGO_FK_JAC) variant = (A.out ? 1 : 0) | (A.out2 ? 2 : 0);
     else if (algo == BRBD_ALGO_RNEA_DERIV) variant = m->prezeroed ? 1 : 0;
@@ -265,16 +311,33 @@ int launch_algo(brbd_model* m, int algo, KArgs& A, int layout, hipStream_t strea
     for (int k = 0; k < 8 && sk; ++k) {
       A.nb[k] = 0;
       if (!ptrs[k]) continue;
-      const double span = 8.0 * (layout == BRBD_BATCH_MAJOR ? (double)lds_[k] * (double)dofs[k]
-                                                             : (double)lds_[k] * (double)A.B);
-      if (span >= 4294967295.0) sk = nullptr;
-      else A.nb[k] = (uint32_t)span;
+      const double span = mat_span_bytes(lds_[k], dofs[k], A.B, layout);  // exact: the range check is the bound
+      if (span >= 4294967295.0) {
+        // 32-bit byte offsets: a matrix of 4 GiB or more runs on the (slower) table-driven kernels.
+        // Loud, once per handle: callers should split the batch by columns instead.
+        if (!m->warned_4g) {
+          m->warned_4g = true;
+          fprintf(stderr, "brbd: a boundary matrix of this call spans >= 4 GiB: the model-compiled kernels "
+                          "(32-bit offsets) do not apply, using the table-driven kernels; split the batch by "
+                          "columns to stay on the compiled ones\n");
+        }
+        sk = nullptr;
+      } else {
+        A.nb[k] = (uint32_t)span;
+      }
     }
-    if (sk && !sk->fn[layout][variant]) sk = nullptr;
+    // INSTANCE_MAJOR with tight leading dimensions (what Eigen hands the reference): the kernels
+    // that stage the tile through LDS (brbd_spec.hpp, kernel layout 2)
+    static const bool no_staged = getenv("BRBD_DISABLE_STAGED") && getenv("BRBD_DISABLE_STAGED")[0] == '1';
+    if (sk && layout == BRBD_INSTANCE_MAJOR && !no_staged && (algo == BRBD_ALGO_RNEA || algo == BRBD_ALGO_ABA) &&
+        sk->fn[2][variant] && A.ldq == F.nq && A.ldv == F.nv && A.lda == F.nv && A.ldout == F.nv)
+      klayout = 2;
+    if (sk && !sk->fn[klayout][variant]) sk = nullptr;
   }
   if (algo == BRBD_ALGO_RNEA_DERIV && !sk) return 1;  // caller falls back to the table-driven kernel
   const bool stat = sk != nullptr;
-  SpecFn sfn = stat ? sk->fn[layout][variant] : nullptr;
+  SpecFn sfn = stat ? sk->fn[klayout][variant] : nullptr;
+  const int stage = stat && klayout == 2 ? sk->stage_doubles : 0;
   int& mw = stat ? m->max_waves_spec[algo] : m->max_waves[algo];
   if (mw == 0) {
     int w = 0;
@@ -305,7 +368,7 @@ int launch_algo(brbd_model* m, int algo, KArgs& A, int layout, hipStream_t strea
     per_lane = (stack - lds_cap) + (algo == BRBD_ALGO_ABA ? F.hand_total : 0);
     if (per_lane < 1) per_lane = 1;
   } else if (stat) {
-    per_lane = sk->glb_doubles > 0 ? sk->glb_doubles : 1;  // the storage plan's global park area
+    per_lane = sk->glb_doubles + stage > 0 ? sk->glb_doubles + stage : 1;  // global park area + staging rows
     A.ctab = m->d_ct[algo];
   }
   A.lds_cap = lds_cap;
@@ -315,17 +378,28 @@ int launch_algo(brbd_model* m, int algo, KArgs& A, int layout, hipStream_t strea
   int64_t grid = A.ntiles < resident ? A.ntiles : resident;
   if (stat) {
     static const int rounds = getenv("BRBD_CHUNK_ROUNDS") ? atoi(getenv("BRBD_CHUNK_ROUNDS")) : 8;
-    int64_t chunk = sk->glb_doubles > 0 ? resident * (rounds > 0 ? rounds : 1) : A.ntiles;
+    // (test hook: BRBD_CHUNK_ROUNDS = -n launches n TILES at a time, whatever the kernel parks)
+    int64_t chunk = rounds < 0 ? -rounds : (sk->glb_doubles + stage > 0 ? resident * (rounds > 0 ? rounds : 1) : A.ntiles);
     const int64_t cap = (int64_t)(4000000000.0 / ((double)per_lane * WAVE * 8));  // 32-bit park offsets
     if (chunk > cap) chunk = cap;
     grid = A.ntiles < chunk ? A.ntiles : chunk;
   }
   A.ws_stride = (int64_t)per_lane * WAVE;
-  int rc = ensure_ws(m, (size_t)grid * A.ws_stride);
-  if (rc) return rc;
-  A.ws = m->d_ws;
+  int rc = BRBD_OK;
+  if (fixed) {
+    const int64_t fit = (int64_t)(fixed->doubles / (size_t)A.ws_stride);
+    if (fit < 1)
+      return fail(BRBD_ERR_INVALID_ARGUMENT, "this model needs " + std::to_string(A.ws_stride * 8) +
+                  " bytes of workspace per wave, more than the fixed scratch area holds");
+    if (grid > fit) grid = fit;  // the table-driven kernels stride over the tiles: fewer waves, more rounds
+    A.ws = fixed->ptr;
+  } else {
+    StreamCtx* ctx = get_ctx(m, stream);
+    if ((rc = ensure_buf(&ctx->d_ws, &ctx->ws_doubles, (size_t)grid * A.ws_stride, stream))) return rc;
+    A.ws = ctx->d_ws;
+  }
   A.ws_bytes = (uint32_t)((size_t)grid * A.ws_stride * 8);
-  Timer tm{m, algo, stream};
+  Timer tm{m, fixed ? -1 : algo, stream};
   if ((rc = tm.begin())) return rc;
   const dim3 g((unsigned)grid), b(WAVE);
   if (stat) {
@@ -468,6 +542,13 @@ int brbd_model_create(const brbd_model_desc* desc, int device, brbd_model** out)
     brbd_model_destroy(m);
     return fail(BRBD_ERR_RUNTIME, std::string("uploading the model table: ") + hipGetErrorString(e));
   }
+#ifdef BRBD_SPEC_CHECK
+  if (hipMalloc(&m->d_oob, 8 * sizeof(unsigned long long)) != hipSuccess ||
+      hipMemset(m->d_oob, 0, 8 * sizeof(unsigned long long)) != hipSuccess) {
+    brbd_model_destroy(m);
+    return fail(BRBD_ERR_RUNTIME, "allocating the bounds-check counter");
+  }
+#endif
   *out = m;
   return BRBD_OK;
 }
@@ -484,8 +565,9 @@ int brbd_model_destroy(brbd_model* m) {
   if (m->d_nvsub) (void)hipFree(m->d_nvsub);
   for (double* p : m->d_ct)
     if (p) (void)hipFree(p);
-  if (m->d_ws) (void)hipFree(m->d_ws);
-  if (m->d_stage) (void)hipFree(m->d_stage);
+  for (auto& c : m->ctxs)
+    if (c.second) free_ctx(*c.second);
+  if (m->d_oob) (void)hipFree(m->d_oob);
   delete m;
   return BRBD_OK;
 }
@@ -513,20 +595,113 @@ int64_t brbd_workspace_bytes(const brbd_model* m, int algo, int64_t B) {
   return tiles * WAVE * (int64_t)per_lane * 8;
 }
 
-// ---- host-memspace plumbing: stage through one device buffer, same kernels ------------------
+// ---- host-memspace plumbing ---------------------------------------------------------------------
+// The reference's calling convention: every matrix lives in host memory (Eigen::MatrixXd,
+// algorithm/parallel/rnea.hpp:39-45).  The batch is cut into column chunks that go through two
+// device staging slots on two internal streams: while chunk k computes, chunk k + 1 uploads and
+// chunk k - 1 downloads (PCIe is full duplex).  Copies are 2-D (pitch = the caller's leading
+// dimension, width = the rows / columns that exist), so caller padding is neither read nor written
+// and the device side is always tight.  With pageable host memory the copies block the host and
+// only the kernels overlap; with pinned memory (hipHostMalloc, hipHostRegister / brbd_host_register,
+// torch pin_memory) all three stages overlap.  Results are valid when the call returns.
+extern "C++" {
 namespace {
-struct Staged {
-  brbd_model* m;
-  hipStream_t stream;
-  size_t used = 0;
-  double* take(size_t doubles) {
-    double* p = m->d_stage + used;
-    used += (doubles + 31) & ~size_t(31);
-    return p;
-  }
+
+struct HostMat {
+  const double* src;  // host matrix (uploaded when `up`)
+  double* dst;        // same matrix as an output (downloaded when `down`), else NULL
+  int64_t ld, dof;
+  bool up, down;
 };
+
 size_t padded(size_t doubles) { return (doubles + 31) & ~size_t(31); }
+
+int64_t host_chunk(int64_t B) {
+  static const int64_t forced = getenv("BRBD_HOST_CHUNK") ? atoll(getenv("BRBD_HOST_CHUNK")) : 0;
+  if (forced > 0) return ((forced + WAVE - 1) / WAVE) * WAVE;
+  int64_t c = ((B / 4 + WAVE - 1) / WAVE) * WAVE;  // >= 4 chunks in flight for a large batch
+  if (c < 4096) c = 4096;
+  if (c > 32768) c = 32768;
+  return c;
+}
+
+// launch(Bc, dev, ldd, stream): run the kernels on one chunk; dev[i] / ldd[i] = device image of mats[i]
+template <typename Launch>
+int host_pipeline(brbd_model* m, int64_t B, int layout, const HostMat* mats, int nm, hipStream_t user,
+                  Launch launch) {
+  StreamCtx* ctx = get_ctx(m, user);
+  const int64_t C = host_chunk(B) < B ? host_chunk(B) : ((B + WAVE - 1) / WAVE) * WAVE;
+  const int64_t nchunks = (B + C - 1) / C;
+  size_t off[16], slot = 0;
+  for (int i = 0; i < nm; ++i) {
+    off[i] = slot;
+    slot += padded((size_t)mats[i].dof * (size_t)C);
+  }
+  int rc = ensure_buf(&ctx->d_stage, &ctx->stage_doubles, (nchunks > 1 ? 2 : 1) * slot, user);
+  if (rc) return rc;
+  for (int k = 0; k < 2; ++k) {
+    if (!ctx->pipe[k]) HIP_TRY(hipStreamCreateWithFlags(&ctx->pipe[k], hipStreamNonBlocking));
+    if (!ctx->ev_done[k]) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_done[k], hipEventDisableTiming));
+  }
+  if (!ctx->ev_in) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_in, hipEventDisableTiming));
+  // order the pipeline after what the caller already queued on its stream
+  HIP_TRY(hipEventRecord(ctx->ev_in, user));
+  for (int k = 0; k < 2; ++k) HIP_TRY(hipStreamWaitEvent(ctx->pipe[k], ctx->ev_in, 0));
+
+  const bool bm = layout == BRBD_BATCH_MAJOR;
+  auto copy = [&](int i, int64_t c0, int64_t Bc, double* dev, bool to_device, hipStream_t st) -> hipError_t {
+    const HostMat& M = mats[i];
+    // host block: columns [c0, c0 + Bc); device image tight (ld = dof, or C in BATCH_MAJOR)
+    const size_t spitch = (size_t)M.ld * 8, dpitch = (size_t)(bm ? C : M.dof) * 8;
+    const size_t width = (size_t)(bm ? Bc : M.dof) * 8, height = (size_t)(bm ? M.dof : Bc);
+    const bool flat = spitch == width && dpitch == width;  // tight on both sides: one contiguous block
+    if (to_device) {
+      const double* h = M.src + (bm ? c0 : c0 * M.ld);
+      if (flat) return hipMemcpyAsync(dev, h, width * height, hipMemcpyHostToDevice, st);
+      return hipMemcpy2DAsync(dev, dpitch, h, spitch, width, height, hipMemcpyHostToDevice, st);
+    }
+    double* h = M.dst + (bm ? c0 : c0 * M.ld);
+    if (flat) return hipMemcpyAsync(h, dev, width * height, hipMemcpyDeviceToHost, st);
+    return hipMemcpy2DAsync(h, spitch, dev, dpitch, width, height, hipMemcpyDeviceToHost, st);
+  };
+  auto stage_in = [&](int64_t k) -> int {  // upload + kernels of chunk k
+    const int sl = (int)(k & 1);
+    const int64_t c0 = k * C, Bc = B - c0 < C ? B - c0 : C;
+    double* base = ctx->d_stage + (size_t)sl * slot;
+    double* dev[16];
+    int64_t ldd[16];
+    for (int i = 0; i < nm; ++i) {
+      dev[i] = base + off[i];
+      ldd[i] = bm ? C : mats[i].dof;
+      if (mats[i].up) HIP_TRY(copy(i, c0, Bc, dev[i], true, ctx->pipe[sl]));
+    }
+    return launch(Bc, dev, ldd, ctx->pipe[sl]);
+  };
+  auto stage_out = [&](int64_t k) -> int {
+    const int sl = (int)(k & 1);
+    const int64_t c0 = k * C, Bc = B - c0 < C ? B - c0 : C;
+    double* base = ctx->d_stage + (size_t)sl * slot;
+    for (int i = 0; i < nm; ++i)
+      if (mats[i].down) HIP_TRY(copy(i, c0, Bc, base + off[i], false, ctx->pipe[sl]));
+    return BRBD_OK;
+  };
+  // software pipeline: the upload of chunk k + 1 is queued before the download of chunk k, so that a
+  // host thread blocked in a pageable copy still leaves the GPU with work
+  if ((rc = stage_in(0))) return rc;
+  for (int64_t k = 0; k < nchunks; ++k) {
+    if (k + 1 < nchunks && (rc = stage_in(k + 1))) return rc;
+    if ((rc = stage_out(k))) return rc;
+  }
+  for (int k = 0; k < 2; ++k) {
+    HIP_TRY(hipEventRecord(ctx->ev_done[k], ctx->pipe[k]));
+    HIP_TRY(hipStreamWaitEvent(user, ctx->ev_done[k], 0));
+  }
+  for (int k = 0; k < 2; ++k) HIP_TRY(hipStreamSynchronize(ctx->pipe[k]));
+  return BRBD_OK;
+}
+
 }  // namespace
+}  // extern "C++"
 
 // rnea with (fext != NULL) or without external forces
 static int rnea_impl(brbd_model* m, int64_t B, const double* q, int64_t ldq, const double* v, int64_t ldv,
@@ -544,35 +719,26 @@ static int rnea_impl(brbd_model* m, int64_t B, const double* q, int64_t ldq, con
   DevGuard dg(m->device);
   if (!dg.ok) return fail(BRBD_ERR_RUNTIME, "hipSetDevice failed");
   hipStream_t s = (hipStream_t)stream;
-  KArgs A{};
-  fill_common(m, A, B);
-  A.ldfext = ldf;
   if (memspace == BRBD_DEVICE) {
+    KArgs A{};
+    fill_common(m, A, B);
+    A.ldfext = ldf;
     A.q = q; A.ldq = ldq; A.v = v; A.ldv = ldv; A.a = a; A.lda = lda; A.out = tau; A.ldout = ldtau;
     A.fext = with_fext ? fext : nullptr;
     return launch_algo(m, BRBD_ALGO_RNEA, A, layout, s);
   }
-  const size_t nq_ = mat_span(ldq, F.nq, B, layout), nv_ = mat_span(ldv, F.nv, B, layout),
-               na_ = mat_span(lda, F.nv, B, layout), nt_ = mat_span(ldtau, F.nv, B, layout),
-               nf_ = with_fext ? mat_span(ldf, 6 * (int64_t)F.njoints, B, layout) : 0;
-  if ((rc = ensure_stage(m, padded(nq_) + padded(nv_) + padded(na_) + padded(nt_) + padded(nf_)))) return rc;
-  Staged st{m, s};
-  double *dq = st.take(nq_), *dv = st.take(nv_), *da = st.take(na_), *dt = st.take(nt_);
-  if (with_fext) {
-    double* df = st.take(nf_);
-    HIP_TRY(hipMemcpyAsync(df, fext, nf_ * 8, hipMemcpyHostToDevice, s));
-    A.fext = df;
-  }
-  HIP_TRY(hipMemcpyAsync(dq, q, nq_ * 8, hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync(dv, v, nv_ * 8, hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync(da, a, na_ * 8, hipMemcpyHostToDevice, s));
-  if (ldtau != (layout == BRBD_BATCH_MAJOR ? B : F.nv))  // keep caller padding intact
-    HIP_TRY(hipMemcpyAsync(dt, tau, nt_ * 8, hipMemcpyHostToDevice, s));
-  A.q = dq; A.ldq = ldq; A.v = dv; A.ldv = ldv; A.a = da; A.lda = lda; A.out = dt; A.ldout = ldtau;
-  if ((rc = launch_algo(m, BRBD_ALGO_RNEA, A, layout, s))) return rc;
-  HIP_TRY(hipMemcpyAsync(tau, dt, nt_ * 8, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
-  return BRBD_OK;
+  const HostMat mats[5] = {{q, nullptr, ldq, F.nq, true, false}, {v, nullptr, ldv, F.nv, true, false},
+                           {a, nullptr, lda, F.nv, true, false}, {nullptr, tau, ldtau, F.nv, false, true},
+                           {fext, nullptr, ldf, 6 * (int64_t)F.njoints, true, false}};
+  return host_pipeline(m, B, layout, mats, with_fext ? 5 : 4, s,
+                       [&](int64_t Bc, double** d, const int64_t* ld, hipStream_t st) -> int {
+                         KArgs A{};
+                         fill_common(m, A, Bc);
+                         A.q = d[0]; A.ldq = ld[0]; A.v = d[1]; A.ldv = ld[1]; A.a = d[2]; A.lda = ld[2];
+                         A.out = d[3]; A.ldout = ld[3];
+                         A.fext = with_fext ? d[4] : nullptr; A.ldfext = with_fext ? ld[4] : 0;
+                         return launch_algo(m, BRBD_ALGO_RNEA, A, layout, st);
+                       });
 }
 
 int brbd_rnea(brbd_model* m, int64_t B, const double* q, int64_t ldq, const double* v, int64_t ldv,
@@ -587,9 +753,9 @@ int brbd_rnea_fext(brbd_model* m, int64_t B, const double* q, int64_t ldq, const
   return rnea_impl(m, B, q, ldq, v, ldv, a, lda, fext, ldfext, true, tau, ldtau, layout, memspace, stream);
 }
 
-static int aba_impl(brbd_model* m, int64_t B, const double* q, int64_t ldq, const double* v, int64_t ldv,
-                    const double* tau, int64_t ldtau, const double* fext, int64_t ldf, bool with_fext,
-                    double* ddq, int64_t ldddq, int layout, int memspace, void* stream) {
+static int aba_check(brbd_model* m, int64_t B, const double* q, int64_t ldq, const double* v, int64_t ldv,
+                     const double* tau, int64_t ldtau, const double* fext, int64_t ldf, bool with_fext,
+                     double* ddq, int64_t ldddq, int layout, int memspace) {
   int rc = check_common(m, B, layout, memspace);
   if (rc) return rc;
   const FlatModel& F = m->flat;
@@ -598,40 +764,39 @@ static int aba_impl(brbd_model* m, int64_t B, const double* q, int64_t ldq, cons
   // the reference forgets this check (algorithm/parallel/aba.hpp:62-69 tests `a` only); we add it
   if ((rc = check_mat("tau", tau, ldtau, F.nv, B, layout))) return rc;
   if (with_fext && (rc = check_mat("fext", fext, ldf, 6 * (int64_t)F.njoints, B, layout))) return rc;
-  if ((rc = check_mat("a", ddq, ldddq, F.nv, B, layout))) return rc;
+  return check_mat("a", ddq, ldddq, F.nv, B, layout);
+}
+
+static int aba_impl(brbd_model* m, int64_t B, const double* q, int64_t ldq, const double* v, int64_t ldv,
+                    const double* tau, int64_t ldtau, const double* fext, int64_t ldf, bool with_fext,
+                    double* ddq, int64_t ldddq, int layout, int memspace, void* stream) {
+  int rc = aba_check(m, B, q, ldq, v, ldv, tau, ldtau, fext, ldf, with_fext, ddq, ldddq, layout, memspace);
+  if (rc) return rc;
+  const FlatModel& F = m->flat;
   if (B == 0) return BRBD_OK;
   DevGuard dg(m->device);
   if (!dg.ok) return fail(BRBD_ERR_RUNTIME, "hipSetDevice failed");
   hipStream_t s = (hipStream_t)stream;
-  KArgs A{};
-  fill_common(m, A, B);
-  A.ldfext = ldf;
   if (memspace == BRBD_DEVICE) {
+    KArgs A{};
+    fill_common(m, A, B);
+    A.ldfext = ldf;
     A.q = q; A.ldq = ldq; A.v = v; A.ldv = ldv; A.a = tau; A.lda = ldtau; A.out = ddq; A.ldout = ldddq;
     A.fext = with_fext ? fext : nullptr;
     return launch_algo(m, BRBD_ALGO_ABA, A, layout, s);
   }
-  const size_t nq_ = mat_span(ldq, F.nq, B, layout), nv_ = mat_span(ldv, F.nv, B, layout),
-               nt_ = mat_span(ldtau, F.nv, B, layout), nd_ = mat_span(ldddq, F.nv, B, layout),
-               nf_ = with_fext ? mat_span(ldf, 6 * (int64_t)F.njoints, B, layout) : 0;
-  if ((rc = ensure_stage(m, padded(nq_) + padded(nv_) + padded(nt_) + padded(nd_) + padded(nf_)))) return rc;
-  Staged st{m, s};
-  double *dq = st.take(nq_), *dv = st.take(nv_), *dt = st.take(nt_), *dd = st.take(nd_);
-  if (with_fext) {
-    double* df = st.take(nf_);
-    HIP_TRY(hipMemcpyAsync(df, fext, nf_ * 8, hipMemcpyHostToDevice, s));
-    A.fext = df;
-  }
-  HIP_TRY(hipMemcpyAsync(dq, q, nq_ * 8, hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync(dv, v, nv_ * 8, hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync(dt, tau, nt_ * 8, hipMemcpyHostToDevice, s));
-  if (ldddq != (layout == BRBD_BATCH_MAJOR ? B : F.nv))
-    HIP_TRY(hipMemcpyAsync(dd, ddq, nd_ * 8, hipMemcpyHostToDevice, s));
-  A.q = dq; A.ldq = ldq; A.v = dv; A.ldv = ldv; A.a = dt; A.lda = ldtau; A.out = dd; A.ldout = ldddq;
-  if ((rc = launch_algo(m, BRBD_ALGO_ABA, A, layout, s))) return rc;
-  HIP_TRY(hipMemcpyAsync(ddq, dd, nd_ * 8, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
-  return BRBD_OK;
+  const HostMat mats[5] = {{q, nullptr, ldq, F.nq, true, false}, {v, nullptr, ldv, F.nv, true, false},
+                           {tau, nullptr, ldtau, F.nv, true, false}, {nullptr, ddq, ldddq, F.nv, false, true},
+                           {fext, nullptr, ldf, 6 * (int64_t)F.njoints, true, false}};
+  return host_pipeline(m, B, layout, mats, with_fext ? 5 : 4, s,
+                       [&](int64_t Bc, double** d, const int64_t* ld, hipStream_t st) -> int {
+                         KArgs A{};
+                         fill_common(m, A, Bc);
+                         A.q = d[0]; A.ldq = ld[0]; A.v = d[1]; A.ldv = ld[1]; A.a = d[2]; A.lda = ld[2];
+                         A.out = d[3]; A.ldout = ld[3];
+                         A.fext = with_fext ? d[4] : nullptr; A.ldfext = with_fext ? ld[4] : 0;
+                         return launch_algo(m, BRBD_ALGO_ABA, A, layout, st);
+                       });
 }
 
 int brbd_aba(brbd_model* m, int64_t B, const double* q, int64_t ldq, const double* v, int64_t ldv,
@@ -660,27 +825,22 @@ int brbd_fk_jacobians(brbd_model* m, int64_t B, const double* q, int64_t ldq, do
   DevGuard dg(m->device);
   if (!dg.ok) return fail(BRBD_ERR_RUNTIME, "hipSetDevice failed");
   hipStream_t s = (hipStream_t)stream;
-  KArgs A{};
-  fill_common(m, A, B);
   if (memspace == BRBD_DEVICE) {
+    KArgs A{};
+    fill_common(m, A, B);
     A.q = q; A.ldq = ldq; A.out = J; A.ldout = ldJ; A.out2 = oMi; A.ldout2 = ldoMi;
     return launch_algo(m, BRBD_ALGO_FK_JAC, A, layout, s);
   }
-  const size_t nq_ = mat_span(ldq, F.nq, B, layout);
-  const size_t nj_ = J ? mat_span(ldJ, jd, B, layout) : 0, nm_ = oMi ? mat_span(ldoMi, md, B, layout) : 0;
-  if ((rc = ensure_stage(m, padded(nq_) + padded(nj_) + padded(nm_)))) return rc;
-  Staged st{m, s};
-  double *dq = st.take(nq_), *dJ = J ? st.take(nj_) : nullptr, *dM = oMi ? st.take(nm_) : nullptr;
-  HIP_TRY(hipMemcpyAsync(dq, q, nq_ * 8, hipMemcpyHostToDevice, s));
-  if (J && ldJ != (layout == BRBD_BATCH_MAJOR ? B : jd)) HIP_TRY(hipMemcpyAsync(dJ, J, nj_ * 8, hipMemcpyHostToDevice, s));
-  if (oMi && ldoMi != (layout == BRBD_BATCH_MAJOR ? B : md))
-    HIP_TRY(hipMemcpyAsync(dM, oMi, nm_ * 8, hipMemcpyHostToDevice, s));
-  A.q = dq; A.ldq = ldq; A.out = dJ; A.ldout = ldJ; A.out2 = dM; A.ldout2 = ldoMi;
-  if ((rc = launch_algo(m, BRBD_ALGO_FK_JAC, A, layout, s))) return rc;
-  if (J) HIP_TRY(hipMemcpyAsync(J, dJ, nj_ * 8, hipMemcpyDeviceToHost, s));
-  if (oMi) HIP_TRY(hipMemcpyAsync(oMi, dM, nm_ * 8, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
-  return BRBD_OK;
+  const HostMat mats[3] = {{q, nullptr, ldq, F.nq, true, false}, {nullptr, J, ldJ, J ? jd : 0, false, J != nullptr},
+                           {nullptr, oMi, ldoMi, oMi ? md : 0, false, oMi != nullptr}};
+  return host_pipeline(m, B, layout, mats, 3, s, [&](int64_t Bc, double** d, const int64_t* ld, hipStream_t st) -> int {
+    KArgs A{};
+    fill_common(m, A, Bc);
+    A.q = d[0]; A.ldq = ld[0];
+    A.out = J ? d[1] : nullptr; A.ldout = ld[1];
+    A.out2 = oMi ? d[2] : nullptr; A.ldout2 = ld[2];
+    return launch_algo(m, BRBD_ALGO_FK_JAC, A, layout, st);
+  });
 }
 
 int brbd_joint_jacobian(brbd_model* m, int64_t B, const double* q, int64_t ldq, int joint, int rf,
@@ -719,32 +879,26 @@ int brbd_joint_jacobian(brbd_model* m, int64_t B, const double* q, int64_t ldq, 
     d_chain = it->second.first;
     nchain = it->second.second;
   }
-  KArgs A{};
-  fill_common(m, A, B);
-  A.prog3 = d_chain;
-  A.nops3 = nchain;
-  A.rf = rf;
-  auto run = [&](const double* dq, double* dJ) -> int {
-    A.q = dq; A.ldq = ldq; A.out = dJ; A.ldout = ldJ;
+  auto run = [&](int64_t Bc, const double* dq, int64_t ldq_, double* dJ, int64_t ldJ_, hipStream_t st) -> int {
+    KArgs A{};
+    fill_common(m, A, Bc);
+    A.prog3 = d_chain;
+    A.nops3 = nchain;
+    A.rf = rf;
+    A.q = dq; A.ldq = ldq_; A.out = dJ; A.ldout = ldJ_;
     if (m->max_waves_jjac == 0) m->max_waves_jjac = resident_waves(m, jjac_kernel<1>, WAVE);
     const int64_t grid = A.ntiles < m->max_waves_jjac ? A.ntiles : m->max_waves_jjac;
     const dim3 g((unsigned)grid), b(WAVE);
-    if (layout == BRBD_BATCH_MAJOR) hipLaunchKernelGGL(jjac_kernel<1>, g, b, 0, s, A);
-    else hipLaunchKernelGGL(jjac_kernel<0>, g, b, 0, s, A);
+    if (layout == BRBD_BATCH_MAJOR) hipLaunchKernelGGL(jjac_kernel<1>, g, b, 0, st, A);
+    else hipLaunchKernelGGL(jjac_kernel<0>, g, b, 0, st, A);
     HIP_TRY(hipGetLastError());
     return BRBD_OK;
   };
-  if (memspace == BRBD_DEVICE) return run(q, J);
-  const size_t nq_ = mat_span(ldq, F.nq, B, layout), nj_ = mat_span(ldJ, jd, B, layout);
-  if ((rc = ensure_stage(m, padded(nq_) + padded(nj_)))) return rc;
-  Staged st{m, s};
-  double *dq = st.take(nq_), *dJ = st.take(nj_);
-  HIP_TRY(hipMemcpyAsync(dq, q, nq_ * 8, hipMemcpyHostToDevice, s));
-  if (ldJ != (layout == BRBD_BATCH_MAJOR ? B : jd)) HIP_TRY(hipMemcpyAsync(dJ, J, nj_ * 8, hipMemcpyHostToDevice, s));
-  if ((rc = run(dq, dJ))) return rc;
-  HIP_TRY(hipMemcpyAsync(J, dJ, nj_ * 8, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
-  return BRBD_OK;
+  if (memspace == BRBD_DEVICE) return run(B, q, ldq, J, ldJ, s);
+  const HostMat mats[2] = {{q, nullptr, ldq, F.nq, true, false}, {nullptr, J, ldJ, jd, false, true}};
+  return host_pipeline(m, B, layout, mats, 2, s, [&](int64_t Bc, double** d, const int64_t* ld, hipStream_t st) -> int {
+    return run(Bc, d[0], ld[0], d[1], ld[1], st);
+  });
 }
 
 int brbd_rnea_derivatives(brbd_model* m, int64_t B, const double* q, int64_t ldq, const double* v,
@@ -770,68 +924,94 @@ int brbd_rnea_derivatives(brbd_model* m, int64_t B, const double* q, int64_t ldq
   DevGuard dg(m->device);
   if (!dg.ok) return fail(BRBD_ERR_RUNTIME, "hipSetDevice failed");
   hipStream_t s = (hipStream_t)stream;
-  DerivArgs D{};
-  D.tab = m->d_tab;
-  D.nvsub = m->d_nvsub;
-  D.njoints = F.njoints; D.nq = F.nq; D.nv = F.nv;
-  D.B = B;
-  D.ntiles = (B + WAVE - 1) / WAVE;
-  D.gx = F.gravity[0]; D.gy = F.gravity[1]; D.gz = F.gravity[2];
-  auto run = [&](const double* dq_, const double* dv_, const double* da_, double* pdq, double* pdv,
-                 double* pda, double* pt) -> int {
-    D.q = dq_; D.ldq = ldq; D.v = dv_; D.ldv = ldv; D.a = da_; D.lda = lda;
-    D.dq = pdq; D.lddq = lddq; D.dv = pdv; D.lddv = lddv; D.da = pda; D.ldda = ldda; D.tau = pt; D.ldtau = ldtau;
+  // in[0..2] = q, v, a; out[0..3] = dtau_dq, dtau_dv, dtau_da, tau (the last two may be NULL)
+  auto run = [&](int64_t Bc, const double* const* in, const int64_t* ldi, double* const* out, const int64_t* ldo,
+                 hipStream_t st) -> int {
     if (m->spec && m->use_spec) {  // model-compiled kernel (codegen/deriv.py), when registered
       KArgs A{};
-      fill_common(m, A, B);
-      A.q = dq_; A.ldq = ldq; A.v = dv_; A.ldv = ldv; A.a = da_; A.lda = lda;
-      A.out = pdq; A.ldout = lddq; A.out2 = pdv; A.ldout2 = lddv; A.out3 = pda; A.ldout3 = ldda;
-      A.out4 = pt; A.ldout4 = ldtau;
-      const int r = launch_algo(m, BRBD_ALGO_RNEA_DERIV, A, layout, s);
+      fill_common(m, A, Bc);
+      A.q = in[0]; A.ldq = ldi[0]; A.v = in[1]; A.ldv = ldi[1]; A.a = in[2]; A.lda = ldi[2];
+      A.out = out[0]; A.ldout = ldo[0]; A.out2 = out[1]; A.ldout2 = ldo[1]; A.out3 = out[2]; A.ldout3 = ldo[2];
+      A.out4 = out[3]; A.ldout4 = ldo[3];
+      const int r = launch_algo(m, BRBD_ALGO_RNEA_DERIV, A, layout, st);
       if (r <= 0) return r;  // 1 = no compiled kernel applies
     }
+    DerivArgs D{};
+    D.tab = m->d_tab;
+    D.nvsub = m->d_nvsub;
+    D.njoints = F.njoints; D.nq = F.nq; D.nv = F.nv;
+    D.B = Bc;
+    D.ntiles = (Bc + WAVE - 1) / WAVE;
+    D.gx = F.gravity[0]; D.gy = F.gravity[1]; D.gz = F.gravity[2];
+    D.q = in[0]; D.ldq = ldi[0]; D.v = in[1]; D.ldv = ldi[1]; D.a = in[2]; D.lda = ldi[2];
+    D.dq = out[0]; D.lddq = ldo[0]; D.dv = out[1]; D.lddv = ldo[1]; D.da = out[2]; D.ldda = ldo[2];
+    D.tau = out[3]; D.ldtau = ldo[3];
     if (m->max_waves[BRBD_ALGO_RNEA_DERIV] == 0)
       m->max_waves[BRBD_ALGO_RNEA_DERIV] = resident_waves(m, rnea_deriv_kernel<1>, WAVE);
     const int64_t grid = D.ntiles < m->max_waves[3] ? D.ntiles : m->max_waves[3];
     D.ws_stride = (int64_t)deriv_ws_per_lane(F) * WAVE;
-    int r = ensure_ws(m, (size_t)grid * D.ws_stride);
+    StreamCtx* ctx = get_ctx(m, st);
+    int r = ensure_buf(&ctx->d_ws, &ctx->ws_doubles, (size_t)grid * D.ws_stride, st);
     if (r) return r;
-    D.ws = m->d_ws;
-    Timer tm{m, BRBD_ALGO_RNEA_DERIV, s};
+    D.ws = ctx->d_ws;
+    Timer tm{m, BRBD_ALGO_RNEA_DERIV, st};
     if ((r = tm.begin())) return r;
     const dim3 g((unsigned)grid), b(WAVE);
-    if (layout == BRBD_BATCH_MAJOR) hipLaunchKernelGGL(rnea_deriv_kernel<1>, g, b, 0, s, D);
-    else hipLaunchKernelGGL(rnea_deriv_kernel<0>, g, b, 0, s, D);
+    if (layout == BRBD_BATCH_MAJOR) hipLaunchKernelGGL(rnea_deriv_kernel<1>, g, b, 0, st, D);
+    else hipLaunchKernelGGL(rnea_deriv_kernel<0>, g, b, 0, st, D);
     HIP_TRY(hipGetLastError());
     return tm.end();
   };
-  if (memspace == BRBD_DEVICE) return run(q, v, a, dtau_dq, dtau_dv, dtau_da, tau);
-  const size_t nq_ = mat_span(ldq, F.nq, B, layout), nv_ = mat_span(ldv, F.nv, B, layout),
-               na_ = mat_span(lda, F.nv, B, layout);
-  const size_t n1 = mat_span(lddq, nn, B, layout), n2 = mat_span(lddv, nn, B, layout),
-               n3 = dtau_da ? mat_span(ldda, nn, B, layout) : 0, n4 = tau ? mat_span(ldtau, F.nv, B, layout) : 0;
-  if ((rc = ensure_stage(m, padded(nq_) + padded(nv_) + padded(na_) + padded(n1) + padded(n2) + padded(n3) + padded(n4))))
-    return rc;
-  Staged st{m, s};
-  double *dq_ = st.take(nq_), *dv_ = st.take(nv_), *da_ = st.take(na_);
-  double *p1 = st.take(n1), *p2 = st.take(n2), *p3 = dtau_da ? st.take(n3) : nullptr, *p4 = tau ? st.take(n4) : nullptr;
-  HIP_TRY(hipMemcpyAsync(dq_, q, nq_ * 8, hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync(dv_, v, nv_ * 8, hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync(da_, a, na_ * 8, hipMemcpyHostToDevice, s));
-  // outputs with caller padding: preserve it
-  const int64_t tight_nn = layout == BRBD_BATCH_MAJOR ? B : nn, tight_nv = layout == BRBD_BATCH_MAJOR ? B : F.nv;
-  // (and, under the prezeroed contract, the zeros the kernel will not write)
+  if (memspace == BRBD_DEVICE) {
+    const double* in[3] = {q, v, a};
+    const int64_t ldi[3] = {ldq, ldv, lda};
+    double* out[4] = {dtau_dq, dtau_dv, dtau_da, tau};
+    const int64_t ldo[4] = {lddq, lddv, ldda, ldtau};
+    return run(B, in, ldi, out, ldo, s);
+  }
+  // under the prezeroed contract the kernel leaves the structural zeros alone: the caller's zeros
+  // must be on the device too, so those outputs are uploaded as well
   const bool pz = m->prezeroed;
-  if (pz || lddq != tight_nn) HIP_TRY(hipMemcpyAsync(p1, dtau_dq, n1 * 8, hipMemcpyHostToDevice, s));
-  if (pz || lddv != tight_nn) HIP_TRY(hipMemcpyAsync(p2, dtau_dv, n2 * 8, hipMemcpyHostToDevice, s));
-  if (p3 && (pz || ldda != tight_nn)) HIP_TRY(hipMemcpyAsync(p3, dtau_da, n3 * 8, hipMemcpyHostToDevice, s));
-  if (p4 && ldtau != tight_nv) HIP_TRY(hipMemcpyAsync(p4, tau, n4 * 8, hipMemcpyHostToDevice, s));
-  if ((rc = run(dq_, dv_, da_, p1, p2, p3, p4))) return rc;
-  HIP_TRY(hipMemcpyAsync(dtau_dq, p1, n1 * 8, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(dtau_dv, p2, n2 * 8, hipMemcpyDeviceToHost, s));
-  if (p3) HIP_TRY(hipMemcpyAsync(dtau_da, p3, n3 * 8, hipMemcpyDeviceToHost, s));
-  if (p4) HIP_TRY(hipMemcpyAsync(tau, p4, n4 * 8, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
+  const HostMat mats[7] = {{q, nullptr, ldq, F.nq, true, false}, {v, nullptr, ldv, F.nv, true, false},
+                           {a, nullptr, lda, F.nv, true, false},
+                           {dtau_dq, dtau_dq, lddq, nn, pz, true}, {dtau_dv, dtau_dv, lddv, nn, pz, true},
+                           {dtau_da, dtau_da, ldda, dtau_da ? nn : 0, pz && dtau_da, dtau_da != nullptr},
+                           {nullptr, tau, ldtau, tau ? F.nv : 0, false, tau != nullptr}};
+  return host_pipeline(m, B, layout, mats, 7, s, [&](int64_t Bc, double** d, const int64_t* ld, hipStream_t st) -> int {
+    const double* in[3] = {d[0], d[1], d[2]};
+    double* out[4] = {d[3], d[4], dtau_da ? d[5] : nullptr, tau ? d[6] : nullptr};
+    return run(Bc, in, ld, out, ld + 3, st);
+  });
+}
+
+int64_t brbd_debug_oob_count(brbd_model* m) {
+#ifdef BRBD_SPEC_CHECK
+  if (!m || !m->d_oob) return -1;
+  DevGuard dg(m->device);
+  unsigned long long n[5] = {0, 0, 0, 0, 0};
+  if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(n, m->d_oob, sizeof n, hipMemcpyDeviceToHost) != hipSuccess)
+    return -1;
+  if (n[0])
+    fprintf(stderr, "brbd check: %llu out-of-range accesses; last: kind %llu at byte %llu + %llu of a %llu-byte buffer\n",
+            n[0], n[1], n[2], n[3], n[4]);
+  return (int64_t)n[0];
+#else
+  (void)m;
+  return -1;
+#endif
+}
+
+int brbd_host_register(void* ptr, size_t bytes) {
+  if (!ptr || !bytes) return fail(BRBD_ERR_INVALID_ARGUMENT, "NULL pointer or zero size");
+  // whole pages: the runtime rejects ranges that are not page aligned
+  const uintptr_t page = 4096, lo = (uintptr_t)ptr & ~(page - 1), hi = ((uintptr_t)ptr + bytes + page - 1) & ~(page - 1);
+  HIP_TRY(hipHostRegister((void*)lo, (size_t)(hi - lo), hipHostRegisterDefault));
+  return BRBD_OK;
+}
+
+int brbd_host_unregister(void* ptr) {
+  if (!ptr) return fail(BRBD_ERR_INVALID_ARGUMENT, "NULL pointer");
+  HIP_TRY(hipHostUnregister((void*)((uintptr_t)ptr & ~(uintptr_t)4095)));
   return BRBD_OK;
 }
 

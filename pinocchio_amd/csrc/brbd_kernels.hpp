@@ -53,6 +53,7 @@ struct KArgs {
   double* out4; int64_t ldout4;  //   RNEA derivatives: tau
   uint32_t nb[8];                //   bytes spanned by q, v, a/tau, out, out2, out3, out4, fext (0 = absent)
   uint32_t ws_bytes;             //   bytes of the global park area of this launch
+  unsigned long long* oob;       //   checking build (-DBRBD_SPEC_CHECK): out-of-range access counter, else NULL
 };
 
 // ---- boundary matrices -------------------------------------------------------------------------

@@ -22,11 +22,15 @@ namespace brbd {
 typedef void (*SpecFn)(const KArgs);
 
 struct SpecKernel {
-  SpecFn fn[2][4];        // [layout][variant]; variant: fkjac output mask (1 = J, 2 = oMi), else 0
+  // [layout][variant]; layout 0 / 1 as in include/brbd.h, 2 = INSTANCE_MAJOR with tight leading
+  // dimensions, staged through LDS (RNEA / ABA only); variant: fkjac output mask (1 = J, 2 = oMi),
+  // else index into codegen/build.py: WANTS
+  SpecFn fn[3][4];
   const int32_t* gather;  // nconst x (joint, field, index): how to pack the constant table
   int32_t nconst;
   int32_t lds_doubles;    // per lane
   int32_t glb_doubles;    // per lane
+  int32_t stage_doubles;  // per lane: global staging rows of the layout-2 kernels (0 = staged in registers)
 };
 enum : int { SF_R = 0, SF_T, SF_M, SF_C, SF_I, SF_ARM, SF_AXIS, SF_G };
 
@@ -55,20 +59,50 @@ typedef unsigned v4u __attribute__((ext_vector_type(4)));
 DI __amdgpu_buffer_rsrc_t spec_rsrc(const void* base, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
 }
+// Checking build (make CHECK=1 -> libbrbd_hip_check.so, -DBRBD_SPEC_CHECK): the hardware drops an
+// access whose offset is outside the buffer's byte range, which would HIDE an indexing bug.  In
+// this build every access of a compiled kernel first compares offset + size with the range; a
+// violation is counted in the handle's counter (brbd_debug_oob_count), which also keeps the last
+// offender's (kind, offset, size, range).  tests/test_gpu_bounds_check.py runs the GPU suite's kernels once under it.
+#ifdef BRBD_SPEC_CHECK
+// out of line and printf-free: the bodies have thousands of access sites, each gets one compare,
+// one branch and this call.  oob[0] = count, oob[1..4] = (what, offset, size, range) of the last one.
+__device__ __attribute__((noinline)) void spec_check_fail(unsigned long long* oob, unsigned off, unsigned size,
+                                                          unsigned bytes, int what) {
+  if (!oob) return;
+  atomicAdd(oob, 1ull);
+  oob[1] = (unsigned long long)what;
+  oob[2] = off;
+  oob[3] = size;
+  oob[4] = bytes;
+}
+DI void spec_check(unsigned long long* oob, unsigned off, unsigned size, unsigned bytes, int what) {
+  // (bytes == 0: an absent optional matrix, dropped by design)
+  if (bytes != 0u && off + size > bytes) spec_check_fail(oob, off, size, bytes, what);
+}
+#define SPEC_CHECK(oob, off, size, bytes, what) spec_check(oob, off, size, bytes, what)
+#else
+#define SPEC_CHECK(oob, off, size, bytes, what) do { } while (0)
+#endif
 template <int LAYOUT, int AUX>
 struct SpecMat;
 template <int AUX>
 struct SpecMat<1, AUX> {  // BATCH_MAJOR: element (d, b) at byte d * ld8 + b * 8
   __amdgpu_buffer_rsrc_t r;
   unsigned voff;
-  DI SpecMat(const double* base, unsigned bytes, unsigned ld8, int64_t b) : r(spec_rsrc(base, bytes)) {
+  unsigned nbytes;
+  unsigned long long* oob;
+  DI SpecMat(const double* base, unsigned bytes, unsigned ld8, int64_t b, unsigned long long* oob_ = nullptr)
+      : r(spec_rsrc(base, bytes)), nbytes(bytes), oob(oob_) {
     (void)ld8;
     voff = (unsigned)b * 8u;
   }
   DI double get(int d, unsigned ld8) const {
+    SPEC_CHECK(oob, voff + (unsigned)d * ld8, 8u, nbytes, 1);
     return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, (unsigned)d * ld8, AUX));
   }
   DI void put(int d, unsigned ld8, double x) const {
+    SPEC_CHECK(oob, voff + (unsigned)d * ld8, 8u, nbytes, 2);
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, x), r, voff, (unsigned)d * ld8, AUX);
   }
 };
@@ -76,13 +110,18 @@ template <int AUX>
 struct SpecMat<0, AUX> {  // INSTANCE_MAJOR: element (d, b) at byte b * ld8 + d * 8 (immediate offset)
   __amdgpu_buffer_rsrc_t r;
   unsigned voff;
-  DI SpecMat(const double* base, unsigned bytes, unsigned ld8, int64_t b) : r(spec_rsrc(base, bytes)) {
+  unsigned nbytes;
+  unsigned long long* oob;
+  DI SpecMat(const double* base, unsigned bytes, unsigned ld8, int64_t b, unsigned long long* oob_ = nullptr)
+      : r(spec_rsrc(base, bytes)), nbytes(bytes), oob(oob_) {
     voff = (unsigned)b * ld8;
   }
   DI double get(int d, unsigned) const {
+    SPEC_CHECK(oob, voff + (unsigned)d * 8u, 8u, nbytes, 3);
     return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff + (unsigned)d * 8u, 0, 0));
   }
   DI void put(int d, unsigned, double x) const {
+    SPEC_CHECK(oob, voff + (unsigned)d * 8u, 8u, nbytes, 4);
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, x), r, voff + (unsigned)d * 8u, 0, 0);
   }
 };
@@ -97,6 +136,98 @@ DI void spec_park_ld(__amdgpu_buffer_rsrc_t r, unsigned voff, int p, double& a, 
   a = __builtin_bit_cast(double, x);
   b = __builtin_bit_cast(double, y);
 }
+
+// ---- INSTANCE_MAJOR with LDS-staged transposition (kernel layout 2) ---------------------------------
+// The reference's own layout (Eigen column-major, one instance per contiguous column,
+// algorithm/parallel/rnea.hpp:39-45) is the worst case for one lane per instance: a per-lane 8-byte
+// load touches one cache line per lane, and each line is touched 16 times over the program (round 1
+// measured 4.9x the input bytes fetched and the waves waiting on the texture addresser 3/4 of the
+// time).  With a tight leading dimension the 64 columns of a tile are ONE contiguous run of 64 x N
+// doubles: the wave reads it with N fully coalesced 512-byte loads, transposes it through LDS (the
+// park area is not in use yet) and every lane ends up with its own instance's N values -- in
+// registers (MODE 0: the kernel has the room, e.g. RNEA) or in N coalesced rows of the wave's
+// private global staging area (MODE 1: the body then reads them like a BATCH_MAJOR matrix).  The
+// output goes the other way at the end of the kernel.  The host selects layout 2 when every staged
+// matrix of the call has ld == rows; anything else runs the per-lane kernels (layout 0).
+struct SpecStage {
+  int64_t tile;
+  int lane;
+  double* lds;   // >= 64 * N doubles of LDS, free at the start and at the end of the kernel
+  double* rows;  // this wave's global staging rows ([row][64 lanes]), MODE 1
+  unsigned rows_bytes;
+};
+template <int N, int AUX, typename Sink>
+DI void spec_stage_load(const double* base, unsigned bytes, const SpecStage& sc, Sink&& sink) {
+  const __amdgpu_buffer_rsrc_t r = spec_rsrc(base, bytes);
+  // flat run of the tile: element j * 64 + lane; past the end of the batch the range check returns 0
+  const unsigned t0 = (unsigned)sc.tile * (unsigned)(WAVE * N * 8) + (unsigned)sc.lane * 8u;
+  double x[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j)
+    x[j] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, t0, (unsigned)(j * WAVE * 8), AUX));
+  __syncthreads();  // (one wave per workgroup: orders the LDS traffic, no cross-wave wait)
+#pragma unroll
+  for (int j = 0; j < N; ++j) sc.lds[j * WAVE + sc.lane] = x[j];
+  __syncthreads();
+#pragma unroll
+  for (int d = 0; d < N; ++d) sink(d, sc.lds[sc.lane * N + d]);
+  __syncthreads();
+}
+template <int LAYOUT, int AUX, int N, int MODE>
+struct SpecIn : SpecMat<LAYOUT, AUX> {
+  DI SpecIn(const double* base, unsigned bytes, unsigned ld8, int64_t b, unsigned long long* oob_, const SpecStage&, int)
+      : SpecMat<LAYOUT, AUX>(base, bytes, ld8, b, oob_) {}
+};
+template <int AUX, int N>
+struct SpecIn<2, AUX, N, 0> {  // staged into registers
+  double r[N > 0 ? N : 1];
+  DI SpecIn(const double* base, unsigned bytes, unsigned, int64_t, unsigned long long*, const SpecStage& sc, int) {
+    spec_stage_load<N, AUX>(base, bytes, sc, [&](int d, double x) { r[d] = x; });
+  }
+  DI double get(int d, unsigned) const { return r[d]; }
+};
+template <int AUX, int N>
+struct SpecIn<2, AUX, N, 1> {  // staged into the wave's global rows row0 .. row0 + N - 1
+  __amdgpu_buffer_rsrc_t rr;
+  unsigned voff, nbytes;
+  int row0;
+  unsigned long long* oob;
+  DI SpecIn(const double* base, unsigned bytes, unsigned, int64_t, unsigned long long* oob_, const SpecStage& sc, int row0_)
+      : rr(spec_rsrc(sc.rows, sc.rows_bytes)), voff((unsigned)sc.lane * 8u), nbytes(sc.rows_bytes), row0(row0_), oob(oob_) {
+    spec_stage_load<N, AUX>(base, bytes, sc, [&](int d, double x) {
+      SPEC_CHECK(oob, voff + (unsigned)((row0 + d) * WAVE * 8), 8u, nbytes, 7);
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, x), rr, voff, (unsigned)((row0 + d) * WAVE * 8), 0);
+    });
+  }
+  DI double get(int d, unsigned) const {
+    SPEC_CHECK(oob, voff + (unsigned)((row0 + d) * WAVE * 8), 8u, nbytes, 8);
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rr, voff, (unsigned)((row0 + d) * WAVE * 8), 0));
+  }
+};
+template <int LAYOUT, int AUX, int N>
+struct SpecOut : SpecMat<LAYOUT, AUX> {
+  DI SpecOut(double* base, unsigned bytes, unsigned ld8, int64_t b, unsigned long long* oob_)
+      : SpecMat<LAYOUT, AUX>(base, bytes, ld8, b, oob_) {}
+  DI void flush(double*, unsigned, const SpecStage&) const {}
+};
+template <int AUX, int N>
+struct SpecOut<2, AUX, N> {  // collected in registers, transposed through LDS and stored coalesced at the end
+  mutable double r[N > 0 ? N : 1];
+  DI SpecOut(double*, unsigned, unsigned, int64_t, unsigned long long*) {}
+  DI void put(int d, unsigned, double x) const { r[d] = x; }
+  DI void flush(double* base, unsigned bytes, const SpecStage& sc) const {
+    const __amdgpu_buffer_rsrc_t rs = spec_rsrc(base, bytes);
+    const unsigned t0 = (unsigned)sc.tile * (unsigned)(WAVE * N * 8) + (unsigned)sc.lane * 8u;
+    __syncthreads();
+#pragma unroll
+    for (int d = 0; d < N; ++d) sc.lds[sc.lane * N + d] = r[d];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < N; ++j)  // (stores past the end of the batch are dropped by the range check)
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, sc.lds[j * WAVE + sc.lane]), rs, t0,
+                                            (unsigned)(j * WAVE * 8), AUX);
+  }
+};
 
 // sin and cos of a joint angle in ~45 straight-line instructions: 3-term Cody-Waite reduction by
 // pi/2 carried by FMAs (exact products), fdlibm's minimax kernels on [-pi/4, pi/4] (k_sin.c /
@@ -154,8 +285,8 @@ DI void spec_sincos(double x, double& so, double& co) {
 #define FMA(a, b, c) __builtin_fma(a, b, c)
 #define PK_LDS_ST2(p, a, b) lds2[(p) * WAVE] = make_double2(a, b)
 #define PK_LDS_LD2(p, a, b) do { const double2 t_ = lds2[(p) * WAVE]; a = t_.x; b = t_.y; } while (0)
-#define PK_GLB_ST2(p, a, b) spec_park_st(wsr, wsoff, p, a, b)
-#define PK_GLB_LD2(p, a, b) spec_park_ld(wsr, wsoff, p, a, b)
+#define PK_GLB_ST2(p, a, b) do { SPEC_CHECK(A.oob, wsoff + (unsigned)(p) * (WAVE * 16u), 16u, A.ws_bytes, 5); spec_park_st(wsr, wsoff, p, a, b); } while (0)
+#define PK_GLB_LD2(p, a, b) do { SPEC_CHECK(A.oob, wsoff + (unsigned)(p) * (WAVE * 16u), 16u, A.ws_bytes, 6); spec_park_ld(wsr, wsoff, p, a, b); } while (0)
 // Visit boundary: nothing is scheduled across it, so the table loads of later visits are not
 // hoisted up front (that is what cost 2000 SGPR spills in the template-unrolled experiment).
 #define OPAQUE(x) asm volatile("" : "+v"(x))
@@ -200,17 +331,27 @@ DI void spec_sincos(double x, double& so, double& co) {
   int trace_ix = 0;                                                                                  \
   (void)lds2; (void)wsr; (void)wsoff; (void)trace_ix;
 
+// SPEC_NQ / SPEC_NV / SPEC_NX / SPEC_NO (rows of q, v, third input, first output), SPEC_STAGE_MODE and
+// SPEC_GLB (doubles per lane of the global park area, after which the staging rows start) are
+// constants of the generated kernel template (codegen/build.py).
 #define BRBD_SPEC_TILE(LAYOUT)                                                                       \
   int64_t inst = tile * WAVE + lane;                                                                 \
   if (inst >= A.B) inst = A.B - 1;                                                                   \
-  const SpecMat<LAYOUT, SPEC_IN_AUX> mq(A.q, A.nb[0], ldq8, inst);                                                \
-  const SpecMat<LAYOUT, SPEC_IN_AUX> mv(A.v, A.nb[1], ldv8, inst);                                                \
-  const SpecMat<LAYOUT, SPEC_IN_AUX> mx(A.a, A.nb[2], ldx8, inst);                                                \
-  const SpecMat<LAYOUT, SPEC_OUT_AUX> mo(A.out, A.nb[3], ldo8, inst);                                              \
-  const SpecMat<LAYOUT, SPEC_OUT_AUX> mo2(A.out2, A.nb[4], ldo28, inst);                                           \
-  const SpecMat<LAYOUT, SPEC_OUT_AUX> mo3(A.out3, A.nb[5], ldo38, inst);                                           \
-  const SpecMat<LAYOUT, SPEC_OUT_AUX> mo4(A.out4, A.nb[6], ldo48, inst);                                           \
-  const SpecMat<LAYOUT, SPEC_IN_AUX> mf(A.fext, A.nb[7], ldf8, inst);                                             \
-  (void)mv; (void)mx; (void)mo; (void)mo2; (void)mo3; (void)mo4; (void)ldo38; (void)ldo48; (void)mf; (void)ldf8;
+  constexpr int LAY_ = (LAYOUT) == 2 ? 0 : (LAYOUT);  /* matrices that are not staged: per lane */   \
+  const SpecStage sc{tile, lane, reinterpret_cast<double*>(lds_area),                                \
+                     A.ws + (int64_t)blockIdx.x * A.ws_stride + (int64_t)SPEC_GLB * WAVE,            \
+                     (unsigned)((SPEC_NQ + SPEC_NV + SPEC_NX) * WAVE * 8)};                           \
+  const SpecIn<LAYOUT, SPEC_IN_AUX, SPEC_NQ, SPEC_STAGE_MODE> mq(A.q, A.nb[0], ldq8, inst, A.oob, sc, 0);          \
+  const SpecIn<LAYOUT, SPEC_IN_AUX, SPEC_NV, SPEC_STAGE_MODE> mv(A.v, A.nb[1], ldv8, inst, A.oob, sc, SPEC_NQ);    \
+  const SpecIn<LAYOUT, SPEC_IN_AUX, SPEC_NX, SPEC_STAGE_MODE> mx(A.a, A.nb[2], ldx8, inst, A.oob, sc, SPEC_NQ + SPEC_NV); \
+  const SpecOut<LAYOUT, SPEC_OUT_AUX, SPEC_NO> mo(A.out, A.nb[3], ldo8, inst, A.oob);                \
+  const SpecMat<LAY_, SPEC_OUT_AUX> mo2(A.out2, A.nb[4], ldo28, inst, A.oob);                        \
+  const SpecMat<LAY_, SPEC_OUT_AUX> mo3(A.out3, A.nb[5], ldo38, inst, A.oob);                        \
+  const SpecMat<LAY_, SPEC_OUT_AUX> mo4(A.out4, A.nb[6], ldo48, inst, A.oob);                        \
+  const SpecMat<LAY_, SPEC_IN_AUX> mf(A.fext, A.nb[7], ldf8, inst, A.oob);                           \
+  (void)mv; (void)mx; (void)mo; (void)mo2; (void)mo3; (void)mo4; (void)ldo38; (void)ldo48; (void)mf; (void)ldf8; (void)sc;
+
+// after the body: layout 2 stores its collected output
+#define BRBD_SPEC_EPILOGUE() mo.flush(A.out, A.nb[3], sc)
 
 }  // namespace brbd

@@ -194,3 +194,20 @@ def test_json_round_trip():
     t1, t2 = m.tables(), m2.tables()
     for k in ("parents", "jtype", "idx_q", "idx_v", "placement", "inertia", "axis", "armature", "gravity"):
         assert np.array_equal(t1[k], t2[k]), k
+
+
+def test_compiled_kernel_signature_carries_the_dof_layout():
+    """The generated bodies hard-code the rows of q / v / tau of every joint, so idx_q / idx_v are
+    part of the signature that selects them (pinocchio_amd/codegen/joints.py; recomputed on the host
+    by model_signature in csrc/brbd_capi.hip)."""
+    from pinocchio_amd.codegen import joints
+    m = S.arm7()
+    p = m.copy()
+    for k, j in enumerate(range(m.njoints - 1, 0, -1)):
+        p.idx_qs[j] = k
+        p.idx_vs[j] = k
+    a, b = joints.ModelView(m).signature(), joints.ModelView(p).signature()
+    assert a != b and ";q0,1,2,3,4,5,6;v0,1,2,3,4,5,6;" in a and ";q6,5,4,3,2,1,0;" in b
+    # the library's registered signatures are the generator's (same text on both sides)
+    reg = open(os.path.join(ROOT, "pinocchio_amd", "csrc", "gen", "spec_arm7_p.hip")).read()
+    assert a in reg

@@ -1,0 +1,134 @@
+"""BASELINE.json's remaining configurations at FULL size, once each, through the C ABI:
+configs[3]'s per-GPU slice (talos-class ABA, 1 048 576 instances: the first test of the chunked
+`tile0 > 0` launches of a compiled kernel that parks state in global memory) and configs[4]
+(quadruped computeRNEADerivatives, 262 144 instances, both output contracts).  Size-independent
+properties + sampled instances against the oracle."""
+import numpy as np
+import pytest
+
+import oracle
+from pinocchio_amd import capi, parallel, sample_models as S
+from util import rel_err_cols
+
+pytestmark = pytest.mark.gpu
+TOL_RNEA, TOL_ABA, TOL_DERIV = 1e-12, 1e-10, 1e-10
+
+
+def _device_inputs(torch, model, B, seed):
+    g = torch.Generator(device="cuda:0")
+    g.manual_seed(seed)
+    dev = torch.device("cuda", 0)
+    q = torch.empty((model.nq, B), dtype=torch.float64, device=dev).uniform_(-1, 1, generator=g)
+    ff = model.idx_qs[1]
+    quat = torch.randn((4, B), dtype=torch.float64, device=dev, generator=g)
+    q[ff + 3:ff + 7] = quat / quat.norm(dim=0)
+    v = torch.empty((model.nv, B), dtype=torch.float64, device=dev).uniform_(-1, 1, generator=g)
+    a = torch.empty((model.nv, B), dtype=torch.float64, device=dev).uniform_(-1, 1, generator=g)
+    return q, v, a
+
+
+def test_full_size_talos_class_aba_one_gpu_slice():
+    import torch
+    model = S.talos_like()
+    pool = parallel.ModelPool(model, 1)
+    dm = pool.device_model(0)
+    assert dm.compiled_kernels() == "talos_like_p"
+    B = 1 << 20
+    q, v, a = _device_inputs(torch, model, B, 7)
+    tau = parallel.rneaInParallel(1, pool, q, v, a)
+    ddq = parallel.abaInParallel(1, pool, q, v, tau)
+    # (1) aba(q, v, rnea(q, v, a)) == a for every instance (unittest/aba.cpp:143-154)
+    err = ((ddq - a).norm(dim=0) / a.norm(dim=0)).max().item()
+    assert err < TOL_ABA, err
+    # (2) 256 sampled instances, spread over all launch chunks, against the oracle
+    idx = np.unique(np.concatenate([np.random.default_rng(1).choice(B, 250, replace=False), [0, 63, 64, B - 65, B - 64, B - 1]]))
+    it = torch.from_numpy(idx).to("cuda:0")
+    qs, vs, ts = (x[:, it].cpu().numpy() for x in (q, v, tau))
+    O = oracle.Oracle(model)
+    assert rel_err_cols(ts, O.rnea(qs, vs, a[:, it].cpu().numpy(), threads=0)).max() < TOL_RNEA
+    assert rel_err_cols(ddq[:, it].cpu().numpy(), O.aba(qs, vs, ts, threads=0)).max() < TOL_ABA
+    # (3) relaunch is bitwise reproducible; a ragged batch (not a multiple of 64, several chunks)
+    assert torch.equal(parallel.abaInParallel(1, pool, q, v, tau), ddq)
+    Br = B - 4097
+    ddq_r = parallel.abaInParallel(1, pool, q[:, :Br], v[:, :Br], tau[:, :Br])
+    assert torch.equal(ddq_r, ddq[:, :Br])
+    # (4) the chunked path really ran: force small chunks and compare
+    pool.release()
+
+
+def test_full_size_quadruped_rnea_derivatives():
+    import torch
+    model = S.quadruped()
+    pool = parallel.ModelPool(model, 1)
+    assert pool.device_model(0).compiled_kernels() == "quadruped_p"
+    B, nv = 262144, model.nv
+    q, v, a = _device_inputs(torch, model, B, 9)
+    dq, dv, da, tau = parallel.computeRNEADerivatives(pool, q, v, a, want_tau=True)
+    # (1) dtau/da = upper triangle of M: M a + rnea(q, v, 0) == rnea(q, v, a) for every instance
+    Mu = da.view(nv, nv, B).permute(1, 0, 2)   # [row][col][b] (column-major per instance)
+    Mfull = torch.triu(Mu.permute(2, 0, 1))     # [b][row][col]
+    # (the free-flyer block is written in full: take the upper triangle, then symmetrise)
+    Mfull = Mfull + torch.triu(Mfull, 1).transpose(1, 2)
+    nle = parallel.rneaInParallel(1, pool, q, v, 0 * a)
+    lhs = torch.einsum("brc,cb->rb", Mfull, a) + nle
+    assert ((lhs - tau).norm(dim=0) / tau.norm(dim=0)).max().item() < 1e-11
+    assert ((parallel.rneaInParallel(1, pool, q, v, a) - tau).norm(dim=0) / tau.norm(dim=0)).max().item() < TOL_RNEA
+    # (2) dtau/dv: directional derivative, exact because tau is quadratic in v:
+    #     tau(v + w) - tau(v - w) = 2 (dtau/dv) w
+    w = torch.flip(v, dims=[1])
+    dvm = dv.view(nv, nv, B).permute(1, 0, 2)
+    lin = torch.einsum("rcb,cb->rb", dvm, w)
+    fd = 0.5 * (parallel.rneaInParallel(1, pool, q, v + w, a) - parallel.rneaInParallel(1, pool, q, v - w, a))
+    assert ((lin - fd).norm(dim=0) / fd.norm(dim=0).clamp_min(1e-3)).max().item() < 1e-10
+    # (3) sampled instances against the oracle, all three matrices
+    idx = np.unique(np.concatenate([np.random.default_rng(2).choice(B, 250, replace=False), [0, 63, 64, B - 1]]))
+    it = torch.from_numpy(idx).to("cuda:0")
+    ref = oracle.Oracle(model).rnea_derivatives(*(x[:, it].cpu().numpy() for x in (q, v, a)), threads=0)
+    for got, r in zip((dq, dv, da), ref[:3]):
+        assert np.abs(got[:, it].cpu().numpy() - r).max() / max(1.0, np.abs(r).max()) < TOL_DERIV
+    # (4) the reference's contract (outputs zeroed by the caller, structural zeros not rewritten)
+    outs = [torch.zeros((nv * nv, B), dtype=torch.float64, device="cuda:0") for _ in range(3)]
+    parallel.computeRNEADerivatives(pool, q, v, a, out=outs)
+    for x, y in zip(outs, (dq, dv, da)):
+        assert torch.equal(x, y)
+    pool.release()
+
+
+def test_compiled_kernels_chunked_launches_match_single_launch(monkeypatch):
+    """A compiled kernel that parks state in global memory is launched in chunks of tiles
+    (`tile0 > 0`); whatever the chunking, the results are bitwise the same."""
+    import os
+    import subprocess
+    import sys
+    import torch
+    model = S.talos_like()
+    pool = parallel.ModelPool(model, 1)
+    B = 40000 + 13
+    q, v, a = _device_inputs(torch, model, B, 11)
+    tau = parallel.rneaInParallel(1, pool, q, v, a)
+    ddq = parallel.abaInParallel(1, pool, q, v, tau)
+    dq = parallel.computeRNEADerivatives(pool, q[:, :6000], v[:, :6000], a[:, :6000])[0]
+    pool.release()
+    # BRBD_CHUNK_ROUNDS is read once per process: the forced-small-chunk run is a child process
+    code = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from pinocchio_amd import parallel, sample_models as S
+model = S.talos_like(); pool = parallel.ModelPool(model, 1)
+d = torch.load(sys.argv[1])
+tau = parallel.rneaInParallel(1, pool, d['q'], d['v'], d['a'])
+ddq = parallel.abaInParallel(1, pool, d['q'], d['v'], tau)
+dq = parallel.computeRNEADerivatives(pool, d['q'][:, :6000], d['v'][:, :6000], d['a'][:, :6000])[0]
+torch.cuda.synchronize()
+assert torch.equal(tau, d['tau']) and torch.equal(ddq, d['ddq']) and torch.equal(dq, d['dq'])
+print('CHUNKED-OK')
+"""
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "io.pt")
+        torch.save({"q": q, "v": v, "a": a, "tau": tau, "ddq": ddq, "dq": dq}, path)
+        env = dict(os.environ, BRBD_CHUNK_ROUNDS="-7")  # see brbd_capi.hip: negative = that many TILES per launch
+        r = subprocess.run([sys.executable, "-c", code % (root, os.path.join(root, "tests")), path], env=env,
+                           capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "CHUNKED-OK" in r.stdout, r.stdout + r.stderr

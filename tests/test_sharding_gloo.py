@@ -1,9 +1,10 @@
 """Multi-GPU path rehearsed on CPU: world_size 2, gloo.  The path shards trivially (independent
 instances): each rank owns the contiguous column range [r*B/G, (r+1)*B/G) and there is
 no collective on the data path; only the timing barrier and the MAX-reduce of bench.py are
-exercised here, with the oracle standing in for the device (the product path has no CPU mode)."""
+exercised here, with the oracle standing in for the device (the product path has no CPU mode).
+The ranks are started by pinocchio_amd/launch.py: spawn_ranks, the launcher `bench.py --gpus N`
+itself uses when it is not already running under torchrun."""
 import os
-import socket
 import subprocess
 import sys
 import textwrap
@@ -50,20 +51,56 @@ WORKER = textwrap.dedent("""
 """)
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+def _run_through_launcher(tmp_path, script_text, world):
+    """Runs `world` ranks of a worker through launch.spawn_ranks in a GPU-free parent process, the
+    way `python bench.py --gpus N` does, and returns (exit code, stdout of rank 0, stderr)."""
+    script = tmp_path / "worker.py"
+    script.write_text(script_text)
+    parent = tmp_path / "parent.py"
+    parent.write_text(textwrap.dedent("""
+        import sys
+        sys.path.insert(0, %r)
+        from pinocchio_amd import launch
+        assert "torch" not in sys.modules  # the parent stays torch- and GPU-free
+        raise SystemExit(launch.spawn_ranks(%d, [%r], timeout=280))
+    """) % (ROOT, world, str(script)))
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, str(parent)], env=env, capture_output=True, text=True, timeout=300)
+    return r.returncode, r.stdout, r.stderr
 
 
 def test_two_rank_sharding(tmp_path):
-    script = tmp_path / "worker.py"
-    script.write_text(WORKER % (ROOT, ROOT))
-    env = dict(os.environ, OMP_NUM_THREADS="2")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stdout + r.stderr
-    assert "OK" in r.stdout
+    rc, out, err = _run_through_launcher(tmp_path, WORKER % (ROOT, ROOT), 2)
+    assert rc == 0, out + err
+    assert "OK" in out
+
+
+def test_launcher_reports_a_failed_rank(tmp_path):
+    rc, out, err = _run_through_launcher(
+        tmp_path, "import os, sys\nsys.exit(3 if os.environ['RANK'] == '1' else 0)\n", 2)
+    assert rc == 3
+
+
+def test_bench_gpus_flag_spawns_ranks_before_touching_the_gpu(tmp_path):
+    """`python bench.py --gpus 2` outside torchrun must start 2 ranks (here they stop at the
+    'needs a GPU' check, which proves WORLD_SIZE reached them) and propagate the failure."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env["BRBD_BENCH_ECHO_RANK"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert "bench rank 0/2" in r.stderr and "bench rank 1/2" in r.stderr, r.stderr
+    import torch
+    if not torch.cuda.is_available():
+        assert r.returncode != 0 and "needs a GPU" in r.stderr
+
+
+def test_column_slices_partition_the_batch():
+    from pinocchio_amd import launch
+    for B, G in ((65536, 8), (1000, 3), (7, 8)):
+        edges = [launch.column_slice(B, r, G) for r in range(G)]
+        assert edges[0][0] == 0 and edges[-1][1] == B
+        assert all(edges[i][1] == edges[i + 1][0] for i in range(G - 1))

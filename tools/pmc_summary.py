@@ -14,7 +14,7 @@ root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
 acc = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(os.path.join(root, "*", "*counter_collection.csv")):
     per_dispatch = defaultdict(float)
-    names = {}
+    names, grids = {}, {}
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"]
         if "brbd::" not in k:
@@ -22,8 +22,15 @@ for f in glob.glob(os.path.join(root, "*", "*counter_collection.csv")):
         key = (row["Dispatch_Id"], row["Counter_Name"])
         per_dispatch[key] += float(row["Counter_Value"])
         names[row["Dispatch_Id"]] = k.split("(")[0].replace("void ", "")
+        grids[row["Dispatch_Id"]] = int(row["Grid_Size"])
+    # only the full-batch dispatches of each kernel (the host-memspace pipeline launches the same
+    # kernels on column chunks: smaller grids, not comparable per launch)
+    full = defaultdict(int)
+    for d, k in names.items():
+        full[k] = max(full[k], grids[d])
     for (d, c), v in per_dispatch.items():
-        acc[names[d]][c].append(v)
+        if grids[d] == full[names[d]]:
+            acc[names[d]][c].append(v)
 out = {}
 for k in sorted(acc):
     out[k] = {c: sum(v) / len(v) for c, v in sorted(acc[k].items())}

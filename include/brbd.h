@@ -166,6 +166,21 @@ int brbd_aba_fext(brbd_model* m, int64_t B, const double* q, int64_t ldq, const 
                   const double* tau, int64_t ldtau, const double* fext, int64_t ldfext, double* ddq,
                   int64_t ldddq, int layout, int memspace, void* stream);
 
+/* brbd_aba for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE: it exists for
+ * callers that must not call hipMalloc -- code under HIP graph capture, tight serving loops,
+ * harnesses that forbid allocation.  Same arguments and results as brbd_aba with BRBD_DEVICE
+ * pointers (asynchronous on `stream`), but it always runs the table-driven ABA kernel and that
+ * kernel's workspace (pass-2 -> pass-3 hand-off records, live-state stack overflow) is a fixed
+ * 64 MiB file-scope device array instead of a buffer the handle allocates and grows.  The call
+ * allocates and frees nothing (no hipMalloc / hipFree / events).  Limits: B <= 1 048 576 per call
+ * (BRBD_ERR_INVALID_ARGUMENT beyond), and a model whose workspace for ONE wave of 64 instances
+ * exceeds 64 MiB is rejected; a batch larger than the array holds at once runs with fewer waves
+ * (the kernel strides over the tiles).  Every GPU the library runs on holds its own copy of the
+ * array until the process ends; all calls on one GPU share it, so calls that overlap on one GPU
+ * (different streams or handles) race: serialise them. */
+int brbd_aba_noalloc(brbd_model* m, int64_t B, const double* q, int64_t ldq, const double* v, int64_t ldv,
+                     const double* tau, int64_t ldtau, double* ddq, int64_t ldddq, int layout, void* stream);
+
 /* Page-lock / release a host range (hipHostRegister / hipHostUnregister) so that BRBD_HOST calls on
  * matrices inside it copy by DMA and overlap upload, kernels and download; the caller must
  * unregister before freeing the memory.  Optional: pageable memory works, only slower.  No

@@ -77,6 +77,7 @@ struct brbd_model {
   int* d_nvsub = nullptr;
   std::map<hipStream_t, std::unique_ptr<StreamCtx>> ctxs;
   unsigned long long* d_oob = nullptr;  // checking build: out-of-range access counter of the compiled kernels
+  double* scratch = nullptr;  // this device's copy of the file-scope scratch array (brbd_aba_noalloc)
   // per-algorithm launch geometry (waves resident on the device)
   int max_waves[4] = {0, 0, 0, 0};
   int max_waves_spec[4] = {0, 0, 0, 0};
@@ -488,6 +489,8 @@ int brbd_model_canonical_form(const brbd_model_desc* desc, int32_t* jtype, doubl
   return BRBD_OK;
 }
 
+static int resolve_scratch(brbd_model* m);  // (no-alloc variant, below)
+
 int brbd_model_create(const brbd_model_desc* desc, int device, brbd_model** out) {
   if (!out) return fail(BRBD_ERR_INVALID_ARGUMENT, "out is NULL");
   *out = nullptr;
@@ -549,6 +552,14 @@ int brbd_model_create(const brbd_model_desc* desc, int device, brbd_model** out)
     return fail(BRBD_ERR_RUNTIME, "allocating the bounds-check counter");
   }
 #endif
+  // no-alloc variant: this device's address of the file-scope scratch array, and the launch
+  // geometry of its kernel, resolved here so that brbd_aba_noalloc itself only launches
+  if (resolve_scratch(m) != BRBD_OK) {
+    const std::string msg = g_err;
+    brbd_model_destroy(m);
+    return fail(BRBD_ERR_RUNTIME, msg);
+  }
+  m->max_waves[BRBD_ALGO_ABA] = resident_waves(m, aba_kernel<1>, WAVE);
   *out = m;
   return BRBD_OK;
 }
@@ -982,6 +993,46 @@ int brbd_rnea_derivatives(brbd_model* m, int64_t B, const double* q, int64_t ldq
     double* out[4] = {d[3], d[4], dtau_da ? d[5] : nullptr, tau ? d[6] : nullptr};
     return run(Bc, in, ld, out, ld + 3, st);
   });
+}
+
+// ---- no-alloc variant ---------------------------------------------------------------------------
+// brbd_aba for callers that cannot allocate (HIP graph capture, serving loops, harnesses that
+// forbid hipMalloc): device memory only, always the table-driven ABA kernel, whose workspace (the
+// pass-2 -> pass-3 hand-off records and the part of the live-state stack that does not fit LDS)
+// lives in the file-scope array below instead of a hipMalloc'ed buffer.  Nothing is allocated or
+// freed here: no hipMalloc / hipFree, no events, no host containers.  Each GPU holds its own copy
+// of the array (64 MiB) from module load to process exit; its address is resolved once per device
+// in brbd_model_create (hipGetSymbolAddress) and kept in the handle.  Every call on a GPU shares
+// that GPU's array: calls that overlap on one GPU (two streams, two handles) race -- serialise
+// them.  Nothing in the array needs clearing: the kernel writes every slot before it reads it.
+#define BRBD_NOALLOC_SCRATCH_DOUBLES (8u * 1024u * 1024u)
+#define BRBD_NOALLOC_MAX_BATCH (1 << 20)
+static __device__ __align__(256) double scratch[BRBD_NOALLOC_SCRATCH_DOUBLES];
+
+static int resolve_scratch(brbd_model* m) {  // (device m->device is current)
+  double* ptr = nullptr;
+  HIP_TRY(hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch)));
+  if (!ptr) return fail(BRBD_ERR_RUNTIME, "hipGetSymbolAddress(scratch) returned NULL");
+  m->scratch = ptr;
+  return BRBD_OK;
+}
+
+int brbd_aba_noalloc(brbd_model* m, int64_t B, const double* q, int64_t ldq, const double* v, int64_t ldv,
+                     const double* tau, int64_t ldtau, double* ddq, int64_t ldddq, int layout, void* stream) {
+  int rc = aba_check(m, B, q, ldq, v, ldv, tau, ldtau, nullptr, 0, false, ddq, ldddq, layout, BRBD_DEVICE);
+  if (rc) return rc;
+  if (B > BRBD_NOALLOC_MAX_BATCH)
+    return fail(BRBD_ERR_INVALID_ARGUMENT, "brbd_aba_noalloc: batch " + std::to_string(B) + " exceeds the maximum of " +
+                                               std::to_string((int64_t)BRBD_NOALLOC_MAX_BATCH) + " instances per call");
+  if (B == 0) return BRBD_OK;
+  if (!m->scratch) return fail(BRBD_ERR_RUNTIME, "the scratch array of this device was not resolved at model creation");
+  DevGuard dg(m->device);
+  if (!dg.ok) return fail(BRBD_ERR_RUNTIME, "hipSetDevice failed");
+  KArgs A{};
+  fill_common(m, A, B);
+  A.q = q; A.ldq = ldq; A.v = v; A.ldv = ldv; A.a = tau; A.lda = ldtau; A.out = ddq; A.ldout = ldddq;
+  const FixedWs fixed{m->scratch, (size_t)BRBD_NOALLOC_SCRATCH_DOUBLES};
+  return launch_algo(m, BRBD_ALGO_ABA, A, layout, (hipStream_t)stream, &fixed);
 }
 
 int64_t brbd_debug_oob_count(brbd_model* m) {

@@ -221,6 +221,30 @@ int brbd_rnea_derivatives(brbd_model* m, int64_t B, const double* q, int64_t ldq
                           double* dtau_dv, int64_t lddv, double* dtau_da, int64_t ldda, double* tau,
                           int64_t ldtau, int layout, int memspace, void* stream);
 
+/* integrate(model, q, v, qout) per instance (algorithm/joint-configuration.hxx; per joint the
+ * Lie-group integrate_impl: liegroup/vector-space.hpp q + v, special-orthogonal.hpp:164-184 (revolute
+ * unbounded), :495-510 (spherical), special-euclidean.hpp:773-812 (free-flyer: q * exp6(v), sign
+ * kept on the hemisphere of q, first-order re-normalisation)).  qout is nq x B; it may not alias q. */
+int brbd_integrate(brbd_model* m, int64_t B, const double* q, int64_t ldq, const double* v, int64_t ldv, double* qout,
+                   int64_t ldqout, int layout, int memspace, void* stream);
+
+/* computeMinverse(model, data, q) per instance (algorithm/aba.hxx:841-877): Minv is (nv * nv) x B,
+ * per instance column-major nv x nv; like data.Minv in the reference only the UPPER triangle (and the
+ * diagonal blocks of multi-dof joints) is computed, the strictly lower part is written as zero.
+ * Needs depth-first joint numbering (BRBD_ERR_UNSUPPORTED otherwise). */
+int brbd_minverse(brbd_model* m, int64_t B, const double* q, int64_t ldq, double* Minv, int64_t ldminv, int layout,
+                  int memspace, void* stream);
+
+/* computeABADerivatives(model, data, q, v, tau, ddq_dq, ddq_dv, ddq_dtau) per instance
+ * (algorithm/aba-derivatives.hxx:381-454): three (nv * nv) x B matrices, per instance column-major;
+ * ddq_dtau = Minv, FULL and symmetric (:449-450); ddq_dq = -Minv dtau_dq, ddq_dv = -Minv dtau_dv at
+ * the acceleration ddq = aba(q, v, tau) (:452-453), which is returned in `ddq` (nv x B) unless NULL.
+ * Every element is written.  Depth-first numbering; nv <= 48 in this version. */
+int brbd_aba_derivatives(brbd_model* m, int64_t B, const double* q, int64_t ldq, const double* v, int64_t ldv,
+                         const double* tau, int64_t ldtau, double* ddq_dq, int64_t lddq, double* ddq_dv, int64_t lddv,
+                         double* ddq_dtau, int64_t lddtau, double* ddq, int64_t ldddq, int layout, int memspace,
+                         void* stream);
+
 /* Layout helpers (device): instance-major <-> batch-major transposes used by
  * the INSTANCE_MAJOR entry points; exposed for harnesses.
  * dst/src are device pointers; dof x B logical matrix. */

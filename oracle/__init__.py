@@ -49,6 +49,9 @@ def lib():
         L.brbd_oracle_aba_batch.argtypes = [vp, i64, dp, dp, dp, dp, ctypes.c_int]
         L.brbd_oracle_fk_jacobians_batch.argtypes = [vp, i64, dp, dp, dp, ctypes.c_int]
         L.brbd_oracle_rnea_derivatives_batch.argtypes = [vp, i64, dp, dp, dp, dp, dp, dp, dp, ctypes.c_int]
+        L.brbd_oracle_minverse.argtypes = [vp, dp, dp]
+        L.brbd_oracle_integrate.argtypes = [vp, dp, dp, dp]
+        L.brbd_oracle_aba_derivatives.argtypes = [vp, dp, dp, dp, dp, dp, dp, dp]
         _lib = L
     return _lib
 
@@ -153,6 +156,44 @@ class Oracle:
                                                       _p(da), _p(tau), threads)
         assert rc > 0, rc
         return dq, dv, da, tau
+
+
+def _per_column(fn, ins, out_rows):
+    """Run a single-instance oracle function over the columns of (rows, B) inputs."""
+    B = ins[0].shape[1]
+    outs = [np.zeros((r, B), order="F") for r in out_rows]
+    for b in range(B):
+        cols = [np.ascontiguousarray(x[:, b]) for x in ins]
+        res = [np.zeros(r) for r in out_rows]
+        rc = fn(*[_p(c) for c in cols], *[_p(r) for r in res])
+        assert rc == 0, rc
+        for o, r in zip(outs, res):
+            o[:, b] = r
+    return outs
+
+
+def _minverse(self, q):
+    """computeMinverse per column: (nv*nv, B), per instance column-major, upper triangle."""
+    q = _cols(q, self.nq)
+    return _per_column(lambda *a: lib().brbd_oracle_minverse(self._ref, *a), [q], [self.nv * self.nv])[0]
+
+
+def _integrate(self, q, v):
+    """integrate(model, q, v) per column: (nq, B)."""
+    q, v = _cols(q, self.nq), _cols(v, self.nv)
+    return _per_column(lambda *a: lib().brbd_oracle_integrate(self._ref, *a), [q, v], [self.nq])[0]
+
+
+def _aba_derivatives(self, q, v, tau):
+    """computeABADerivatives per column: ddq_dq, ddq_dv, ddq_dtau (= Minv, full) as (nv*nv, B), ddq (nv, B)."""
+    q, v, tau = _cols(q, self.nq), _cols(v, self.nv), _cols(tau, self.nv)
+    nn = self.nv * self.nv
+    return _per_column(lambda *a: lib().brbd_oracle_aba_derivatives(self._ref, *a), [q, v, tau], [nn, nn, nn, self.nv])
+
+
+Oracle.minverse = _minverse
+Oracle.integrate = _integrate
+Oracle.aba_derivatives = _aba_derivatives
 
 
 def max_threads() -> int:

@@ -1198,6 +1198,258 @@ int brbd_oracle_rnea_derivatives(const brbd_model_desc* m, const double* q, cons
   return 0;
 }
 
+/* ================================================================== computeMinverse */
+/* algorithm/aba.hxx:841-877; pass 1 :626-654, pass 2 :668-728, pass 3 :802-833.  Minv is nv x nv,
+ * written here COLUMN-major like the other per-instance matrices (element (r, c) at c * nv + r);
+ * as in the reference only the UPPER triangle (and the diagonal blocks of multi-dof joints) is
+ * computed, the strictly lower part is zero (data.Minv starts as zeros, :853).  Needs depth-first
+ * numbering (nvSubtree column ranges, like the derivatives). */
+static int minverse_ws(const brbd_model_desc* m, ws_t* w, const double* q, double* Minv) {
+  const int n = m->njoints, nv = m->nv;
+  double* Fcrb = (double*)calloc((size_t)n * 6 * (size_t)(nv > 0 ? nv : 1), sizeof(double)); /* Fcrb[i]: 6 x nv col-major */
+  double* SDinv = (double*)calloc((size_t)6 * (size_t)(nv > 0 ? nv : 1), sizeof(double));
+  if (!Fcrb || !SDinv) return -1;
+#define MINV(r, c) Minv[(size_t)(c) * nv + (r)]
+  for (int k = 0; k < nv * nv; ++k) Minv[k] = 0.0; /* :853 */
+  for (int i = 1; i < n; ++i) {                    /* pass 1 */
+    const int p = m->parents[i];
+    se3_t P;
+    inertia_t Y;
+    get_placement(m, i, &P);
+    get_inertia(m, i, &Y);
+    jdata_t* jd = &w->jd[i];
+    joint_calc(m->jtype[i], &P, get_axis(m, i), q + m->idx_q[i], NULL, &w->liMi[i], jd); /* :636-639 */
+    if (p > 0) se3_mul(&w->oMi[p], &w->liMi[i], &w->oMi[i]);                             /* :641-644 */
+    else w->oMi[i] = w->liMi[i];
+    for (int c = 0; c < jd->nv; ++c) se3_act_motion(&w->oMi[i], jd->S[c], w->J + 6 * (m->idx_v[i] + c)); /* :650 */
+    se3_act_inertia(&w->oMi[i], &Y, &w->Ycrb[i]);  /* :652 */
+    inertia_matrix(&w->Ycrb[i], w->Yaba + 36 * i); /* :653 */
+  }
+  double* F0 = Fcrb; /* data.Fcrb[0].setZero() :863 (calloc) */
+  for (int i = n - 1; i > 0; --i) { /* pass 2 */
+    const int p = m->parents[i];
+    const int nvj = w->jd[i].nv, iv = m->idx_v[i], nsub = w->nvSubtree[i];
+    double* Ia = w->Yaba + 36 * i;
+    double* Jc = w->J + 6 * iv;
+    double* U = w->U + 36 * i;
+    double* UD = w->UDinv + 36 * i;
+    double* Dinv = w->Dinv + 36 * i;
+    double StU[36];
+    for (int c = 0; c < nvj; ++c) mat6_mulvec(Ia, Jc + 6 * c, U + 6 * c); /* :689 */
+    for (int r = 0; r < nvj; ++r)                                        /* :690 */
+      for (int c = 0; c < nvj; ++c) StU[nvj * r + c] = dot6(Jc + 6 * r, U + 6 * c);
+    if (m->armature)
+      for (int c = 0; c < nvj; ++c) StU[nvj * c + c] += m->armature[iv + c]; /* :693 */
+    if (spd_inverse(nvj, StU, Dinv)) { free(Fcrb); free(SDinv); return -1; } /* :695 */
+    for (int c = 0; c < nvj; ++c)                                           /* :696 */
+      for (int k = 0; k < 6; ++k) {
+        double s = 0;
+        for (int r = 0; r < nvj; ++r) s += U[6 * r + k] * Dinv[nvj * r + c];
+        UD[6 * c + k] = s;
+      }
+    for (int r = 0; r < nvj; ++r) /* :698 */
+      for (int c = 0; c < nvj; ++c) MINV(iv + r, iv + c) = Dinv[nvj * r + c];
+    const int nch = nsub - nvj; /* :699 */
+    if (nch > 0) {
+      for (int c = 0; c < nvj; ++c) /* :703 SDinv_cols = J_cols * Dinv */
+        for (int k = 0; k < 6; ++k) {
+          double s = 0;
+          for (int r = 0; r < nvj; ++r) s += Jc[6 * r + k] * Dinv[nvj * r + c];
+          SDinv[6 * (iv + c) + k] = s;
+        }
+      for (int r = 0; r < nvj; ++r) /* :705-707 */
+        for (int c = 0; c < nch; ++c) MINV(iv + r, iv + nvj + c) = -dot6(SDinv + 6 * (iv + r), F0 + 6 * (iv + nvj + c));
+      if (p > 0) /* :709-715 Fcrb[0].middleCols(iv, nsub) += U * Minv.block(iv, iv, nvj, nsub) */
+        for (int c = 0; c < nsub; ++c)
+          for (int k = 0; k < 6; ++k) {
+            double s = 0;
+            for (int r = 0; r < nvj; ++r) s += U[6 * r + k] * MINV(iv + r, iv + c);
+            F0[6 * (iv + c) + k] += s;
+          }
+    } else { /* :717-721 */
+      for (int c = 0; c < nsub; ++c)
+        for (int k = 0; k < 6; ++k) {
+          double s = 0;
+          for (int r = 0; r < nvj; ++r) s += U[6 * r + k] * MINV(iv + r, iv + c);
+          F0[6 * (iv + c) + k] = s;
+        }
+    }
+    if (p > 0) { /* :723-727 */
+      for (int r = 0; r < 6; ++r)
+        for (int c = 0; c < 6; ++c) {
+          double s = 0;
+          for (int k = 0; k < nvj; ++k) s += UD[6 * k + r] * U[6 * k + c];
+          Ia[6 * r + c] -= s;
+        }
+      for (int k = 0; k < 36; ++k) w->Yaba[36 * p + k] += Ia[k];
+    }
+  }
+  for (int i = 1; i < n; ++i) { /* pass 3 */
+    const int p = m->parents[i];
+    const int nvj = w->jd[i].nv, iv = m->idx_v[i];
+    double* Jc = w->J + 6 * iv;
+    double* UD = w->UDinv + 36 * i;
+    double* Fi = Fcrb + (size_t)i * 6 * nv;
+    double* Fp = Fcrb + (size_t)p * 6 * nv;
+    if (p > 0) /* :819-825 Minv.middleRows(iv, nvj).rightCols(nv - iv) -= UDinv^T * Fcrb[parent].rightCols(nv - iv) */
+      for (int r = 0; r < nvj; ++r)
+        for (int c = iv; c < nv; ++c) MINV(iv + r, c) -= dot6(UD + 6 * r, Fp + 6 * c);
+    for (int c = iv; c < nv; ++c) /* :827-829 Fcrb[i].rightCols = J_cols * Minv.middleRows(iv, nvj).rightCols */
+      for (int k = 0; k < 6; ++k) {
+        double s = 0;
+        for (int r = 0; r < nvj; ++r) s += Jc[6 * r + k] * MINV(iv + r, c);
+        Fi[6 * c + k] = s;
+      }
+    if (p > 0) /* :830-832 */
+      for (int c = iv; c < nv; ++c)
+        for (int k = 0; k < 6; ++k) Fi[6 * c + k] += Fp[6 * c + k];
+  }
+#undef MINV
+  free(Fcrb);
+  free(SDinv);
+  return 0;
+}
+
+int brbd_oracle_minverse(const brbd_model_desc* m, const double* q, double* Minv) {
+  if (check_model(m) || !q || !Minv) return -1;
+  ws_t* w = ws_alloc(m);
+  const int rc = minverse_ws(m, w, q, Minv);
+  ws_free(w);
+  return rc;
+}
+
+/* ================================================================== integrate */
+/* algorithm/joint-configuration.hxx integrate(model, q, v, qout): per joint the Lie-group
+ * integrate_impl of its configuration space.
+ *   vector spaces (revolute, prismatic, unaligned): q + v
+ *   SO(2), revolute unbounded: multibody/liegroup/special-orthogonal.hpp:164-184
+ *   SO(3), spherical:          special-orthogonal.hpp:495-510
+ *   SE(3), free-flyer:         special-euclidean.hpp:773-812
+ * quaternion::exp3 spatial/explog-quaternion.hpp:25-66, exp6 :92-136,
+ * firstOrderNormalize math/quaternion.hpp:89-112, Taylor precision math/taylor-expansion.hpp:31-36 */
+static double ts_prec3(void) { return sqrt(sqrt(2.220446049250313e-16)); } /* eps^(1/4) */
+
+static void quat_exp3(const double* v, double* qo) { /* explog-quaternion.hpp:25-66; qo = (x, y, z, w) */
+  const double eps = 2.220446049250313e-16;
+  const double t2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+  const double t = sqrt(t2 + eps * eps);
+  if (t2 > ts_prec3()) { /* Eigen::AngleAxis(t, v / t) -> quaternion */
+    double s, c;
+    sincos(0.5 * t, &s, &c);
+    for (int k = 0; k < 3; ++k) qo[k] = s * (v[k] / t);
+    qo[3] = c;
+  } else { /* order-4 Taylor expansion */
+    const double t2_2 = t2 / 4;
+    const double a = 0.5 * (1.0 - t2_2 / 6.0 + t2_2 * t2_2 / 120.0);
+    for (int k = 0; k < 3; ++k) qo[k] = a * v[k];
+    qo[3] = 1.0 - t2_2 / 2 + t2_2 * t2_2 / 24;
+  }
+}
+static void quat_mul(const double* a, const double* b, double* o) { /* Eigen quaternion product, (x, y, z, w) */
+  const double x = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+  const double y = a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2];
+  const double z = a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0];
+  const double ww = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+  o[0] = x; o[1] = y; o[2] = z; o[3] = ww;
+}
+static void quat_first_order_normalize(double* q) { /* math/quaternion.hpp:89-112 */
+  const double N2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+  const double alpha = (3.0 - N2) / 2.0;
+  for (int k = 0; k < 4; ++k) q[k] *= alpha;
+}
+
+int brbd_oracle_integrate(const brbd_model_desc* m, const double* q, const double* v, double* qout) {
+  if (check_model(m) || !q || !v || !qout) return -1;
+  for (int i = 1; i < m->njoints; ++i) {
+    const int jt = m->jtype[i], iq = m->idx_q[i], iv = m->idx_v[i];
+    if (jt == BRBD_JOINT_FREEFLYER) { /* special-euclidean.hpp:773-812 */
+      const double* lin = v + iv;
+      const double* wv = v + iv + 3;
+      const double eps = 2.220446049250313e-16;
+      const double t2 = wv[0] * wv[0] + wv[1] * wv[1] + wv[2] * wv[2] + eps * eps; /* exp6 :106-107 */
+      const double t = sqrt(t2);
+      double st, ct;
+      sincos(t, &st, &ct);
+      const double inv_t2 = 1.0 / t2;
+      const double a_wxv = t < ts_prec3() ? 0.5 - t2 / 24.0 : (1.0 - ct) * inv_t2;            /* :119-123 */
+      const double a_w2 = t < ts_prec3() ? 1.0 / 6.0 - t2 / 120.0 : (t - st) * inv_t2 / t;     /* :125-126 */
+      double wxv[3], wwxv[3], trans[3], e3[4];
+      cross3(wv, lin, wxv);
+      cross3(wv, wxv, wwxv);
+      for (int k = 0; k < 3; ++k) trans[k] = lin[k] + a_wxv * wxv[k] + a_w2 * wwxv[k]; /* :130 */
+      quat_exp3(wv, e3);                                                               /* :135 */
+      double R[9], rt[3];
+      quat_to_R(q + iq + 3, R); /* quat * vec3: Eigen rotates through the rotation matrix of quat */
+      matvec3(R, trans, rt);
+      for (int k = 0; k < 3; ++k) qout[iq + k] = rt[k] + q[iq + k]; /* :796 */
+      double res[4];
+      quat_mul(q + iq + 3, e3, res);                                /* :799 */
+      const double dotp = res[0] * q[iq + 3] + res[1] * q[iq + 4] + res[2] * q[iq + 5] + res[3] * q[iq + 6];
+      if (dotp < 0) /* :801-807 */
+        for (int k = 0; k < 4; ++k) res[k] = -res[k];
+      quat_first_order_normalize(res); /* :812 */
+      for (int k = 0; k < 4; ++k) qout[iq + 3 + k] = res[k];
+    } else if (jt == BRBD_JOINT_SPHERICAL) { /* special-orthogonal.hpp:495-510 */
+      double e3[4], res[4];
+      quat_exp3(v + iv, e3);
+      quat_mul(q + iq, e3, res);
+      quat_first_order_normalize(res);
+      for (int k = 0; k < 4; ++k) qout[iq + k] = res[k];
+    } else if ((jt >= BRBD_JOINT_RUBX && jt <= BRBD_JOINT_RUBZ) || jt == BRBD_JOINT_REVOLUTE_UNBOUNDED_UNALIGNED) {
+      /* special-orthogonal.hpp:164-184 */
+      const double ca = q[iq], sa = q[iq + 1];
+      double so, co;
+      sincos(v[iv], &so, &co);
+      double o0 = co * ca - so * sa, o1 = so * ca + co * sa;
+      const double norm2 = o0 * o0 + o1 * o1;
+      const double f = (3 - norm2) / 2;
+      qout[iq] = o0 * f;
+      qout[iq + 1] = o1 * f;
+    } else { /* vector space: liegroup/vector-space.hpp integrate_impl: q + v */
+      qout[iq] = q[iq] + v[iv];
+    }
+  }
+  return 0;
+}
+
+/* ================================================================== computeABADerivatives */
+/* algorithm/aba-derivatives.hxx:381-454.  The reference computes Minv and ddq (passes 1-3), the
+ * partial derivatives of RNEA at that acceleration (pass 4), symmetrises Minv (:449-450) and ends
+ * with (:452-453)   ddq_dq = -Minv * dtau_dq,   ddq_dv = -Minv * dtau_dv,   ddq_dtau = Minv.
+ * Restated with the building blocks above: aba (WORLD), computeRNEADerivatives at a = ddq,
+ * computeMinverse.  All matrices nv x nv column-major; ddq may be NULL. */
+int brbd_oracle_aba_derivatives(const brbd_model_desc* m, const double* q, const double* v, const double* tau,
+                                double* ddq_dq, double* ddq_dv, double* Minv, double* ddq_out) {
+  if (check_model(m) || !q || !v || !tau || !ddq_dq || !ddq_dv || !Minv) return -1;
+  const int nv = m->nv;
+  const size_t nn = (size_t)nv * nv;
+  double* ddq = (double*)calloc((size_t)nv + 1, sizeof(double));
+  double* dq = (double*)calloc(nn + 1, sizeof(double));
+  double* dv = (double*)calloc(nn + 1, sizeof(double));
+  int rc = brbd_oracle_aba_world(m, q, v, tau, ddq);
+  if (!rc) rc = brbd_oracle_rnea_derivatives(m, q, v, ddq, dq, dv, NULL, NULL);
+  if (!rc) rc = brbd_oracle_minverse(m, q, Minv);
+  if (!rc) {
+    for (int r = 0; r < nv; ++r) /* :449-450 */
+      for (int c = 0; c < r; ++c) Minv[(size_t)c * nv + r] = Minv[(size_t)r * nv + c];
+    for (int c = 0; c < nv; ++c) /* :452-453 */
+      for (int r = 0; r < nv; ++r) {
+        double s1 = 0, s2 = 0;
+        for (int k = 0; k < nv; ++k) {
+          s1 += Minv[(size_t)k * nv + r] * dq[(size_t)c * nv + k];
+          s2 += Minv[(size_t)k * nv + r] * dv[(size_t)c * nv + k];
+        }
+        ddq_dq[(size_t)c * nv + r] = -s1;
+        ddq_dv[(size_t)c * nv + r] = -s2;
+      }
+    if (ddq_out) memcpy(ddq_out, ddq, (size_t)nv * sizeof(double));
+  }
+  free(ddq);
+  free(dq);
+  free(dv);
+  return rc;
+}
+
 int brbd_oracle_max_threads(void) {
 #ifdef _OPENMP
   /* the batch loops call omp_set_num_threads() like the reference

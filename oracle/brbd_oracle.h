@@ -63,6 +63,17 @@ int brbd_oracle_rnea_derivatives(const brbd_model_desc* m, const double* q, cons
                                  const double* a, double* dtau_dq, double* dtau_dv, double* dtau_da,
                                  double* tau);
 
+/* algorithm/aba.hxx:841-877 computeMinverse: Minv nv x nv column-major, UPPER triangle (plus the
+ * diagonal blocks of multi-dof joints), strictly lower part zero.  Depth-first numbering required. */
+int brbd_oracle_minverse(const brbd_model_desc* m, const double* q, double* Minv);
+/* algorithm/joint-configuration.hxx integrate(model, q, v, qout): qout = q (+) v per joint
+ * (liegroup/special-euclidean.hpp:773-812, special-orthogonal.hpp:164-184, 495-510) */
+int brbd_oracle_integrate(const brbd_model_desc* m, const double* q, const double* v, double* qout);
+/* algorithm/aba-derivatives.hxx:381-454: ddq_dq, ddq_dv, ddq_dtau = Minv (full, symmetric), each
+ * nv x nv column-major; ddq (nv) may be NULL */
+int brbd_oracle_aba_derivatives(const brbd_model_desc* m, const double* q, const double* v, const double* tau,
+                                double* ddq_dq, double* ddq_dv, double* Minv, double* ddq);
+
 /* Batch loops: `#pragma omp parallel for schedule(static)` over instance-major
  * columns with per-thread scratch, as algorithm/parallel/rnea.hpp:70-82.
  * num_threads <= 0 means omp_get_max_threads(). Returns threads used or <0. */

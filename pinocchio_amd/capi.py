@@ -37,6 +37,7 @@ SYMBOLS = (
     "brbd_rnea", "brbd_aba", "brbd_rnea_fext", "brbd_aba_fext", "brbd_fk_jacobians", "brbd_joint_jacobian", "brbd_rnea_derivatives",
     "brbd_transpose_to_batch_major", "brbd_transpose_to_instance_major",
     "brbd_set_timing", "brbd_kernel_time", "brbd_model_compiled_kernels", "brbd_model_use_compiled", "brbd_model_outputs_prezeroed", "brbd_model_canonical_form",
+    "brbd_integrate", "brbd_minverse", "brbd_aba_derivatives",
     "brbd_aba_noalloc", "brbd_host_register", "brbd_host_unregister", "brbd_debug_oob_count",
 )
 
@@ -122,6 +123,12 @@ def lib():
     L.brbd_rnea.argtypes = [vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, ci, ci, vp]
     L.brbd_aba.restype = ci
     L.brbd_aba.argtypes = [vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, ci, ci, vp]
+    L.brbd_integrate.restype = ci
+    L.brbd_integrate.argtypes = [vp, i64, vp, i64, vp, i64, vp, i64, ci, ci, vp]
+    L.brbd_minverse.restype = ci
+    L.brbd_minverse.argtypes = [vp, i64, vp, i64, vp, i64, ci, ci, vp]
+    L.brbd_aba_derivatives.restype = ci
+    L.brbd_aba_derivatives.argtypes = [vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, ci, ci, vp]
     L.brbd_aba_noalloc.restype = ci
     L.brbd_aba_noalloc.argtypes = [vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, ci, vp]
     L.brbd_debug_oob_count.restype = i64

@@ -20,6 +20,7 @@
 #include "brbd_flatten.hpp"
 #include "brbd_kernels.hpp"
 #include "brbd_deriv.hpp"
+#include "brbd_f4.hpp"
 #include "brbd_spec.hpp"
 #include "gen/registry.inc"
 
@@ -63,6 +64,8 @@ struct StreamCtx {
   size_t ws_doubles = 0;
   double* d_stage = nullptr;  // host-memspace path: two chunk slots of device staging
   size_t stage_doubles = 0;
+  double* d_tmp = nullptr;    // brbd_aba_derivatives: the acceleration when the caller does not want it
+  size_t tmp_doubles = 0;
   hipStream_t pipe[2] = {nullptr, nullptr};  // internal streams of the host-memspace pipeline
   hipEvent_t ev_in = nullptr, ev_done[2] = {nullptr, nullptr};
 };
@@ -82,6 +85,7 @@ struct brbd_model {
   int max_waves[4] = {0, 0, 0, 0};
   int max_waves_spec[4] = {0, 0, 0, 0};
   int max_waves_jjac = 0;
+  int max_waves_f4[3] = {0, 0, 0};  // minverse, integrate, aba-derivative products
   std::map<int, std::pair<Op*, int>> chains;  // brbd_joint_jacobian: support chain of a joint (device)
   // model-compiled kernels (brbd_spec.hpp), when the model's signature is registered
   const SpecEntry* spec = nullptr;
@@ -179,6 +183,7 @@ int ensure_buf(double** buf, size_t* have, size_t doubles, hipStream_t s) {
 void free_ctx(StreamCtx& c) {
   if (c.d_ws) (void)hipFree(c.d_ws);
   if (c.d_stage) (void)hipFree(c.d_stage);
+  if (c.d_tmp) (void)hipFree(c.d_tmp);
   for (int k = 0; k < 2; ++k) {
     if (c.ev_done[k]) (void)hipEventDestroy(c.ev_done[k]);
     if (c.pipe[k]) (void)hipStreamDestroy(c.pipe[k]);
@@ -993,6 +998,172 @@ int brbd_rnea_derivatives(brbd_model* m, int64_t B, const double* q, int64_t ldq
     double* out[4] = {d[3], d[4], dtau_da ? d[5] : nullptr, tau ? d[6] : nullptr};
     return run(Bc, in, ld, out, ld + 3, st);
   });
+}
+
+// ---- integrate, computeMinverse, computeABADerivatives ---------------------------
+extern "C++" {
+namespace {
+void fill_f4(const brbd_model* m, F4Args& A, int64_t B) {
+  const FlatModel& F = m->flat;
+  A.tab = m->d_tab;
+  A.prog3 = m->d_prog3;
+  A.nvsub = m->d_nvsub;
+  A.nops3 = (int)F.prog3.size();
+  A.njoints = F.njoints; A.nq = F.nq; A.nv = F.nv; A.maxdepth = F.maxdepth;
+  A.B = B;
+  A.ntiles = (B + WAVE - 1) / WAVE;
+}
+template <typename K>
+int f4_grid(brbd_model* m, int& cache, K kernel, int64_t ntiles) {
+  if (cache == 0) cache = resident_waves(m, kernel, WAVE);
+  return (int)(ntiles < cache ? ntiles : cache);
+}
+int minverse_device(brbd_model* m, int64_t B, const double* q, int64_t ldq, double* Minv, int64_t ldm, int full,
+                    int layout, hipStream_t st) {
+  const FlatModel& F = m->flat;
+  F4Args A{};
+  fill_f4(m, A, B);
+  A.full = full;
+  A.q = q; A.ldq = ldq; A.out = Minv; A.ldout = ldm;
+  const int grid = f4_grid(m, m->max_waves_f4[0], minverse_kernel<1>, A.ntiles);
+  A.ws_stride = (int64_t)minverse_ws_per_lane(F) * WAVE;
+  StreamCtx* ctx = get_ctx(m, st);
+  int rc = ensure_buf(&ctx->d_ws, &ctx->ws_doubles, (size_t)grid * A.ws_stride, st);
+  if (rc) return rc;
+  A.ws = ctx->d_ws;
+  if (layout == BRBD_BATCH_MAJOR) hipLaunchKernelGGL(minverse_kernel<1>, dim3(grid), dim3(WAVE), 0, st, A);
+  else hipLaunchKernelGGL(minverse_kernel<0>, dim3(grid), dim3(WAVE), 0, st, A);
+  HIP_TRY(hipGetLastError());
+  return BRBD_OK;
+}
+}  // namespace
+}  // extern "C++"
+
+int brbd_integrate(brbd_model* m, int64_t B, const double* q, int64_t ldq, const double* v, int64_t ldv, double* qout,
+                   int64_t ldqout, int layout, int memspace, void* stream) {
+  int rc = check_common(m, B, layout, memspace);
+  if (rc) return rc;
+  const FlatModel& F = m->flat;
+  if ((rc = check_mat("q", q, ldq, F.nq, B, layout))) return rc;
+  if ((rc = check_mat("v", v, ldv, F.nv, B, layout))) return rc;
+  if ((rc = check_mat("qout", qout, ldqout, F.nq, B, layout))) return rc;
+  if (B == 0) return BRBD_OK;
+  DevGuard dg(m->device);
+  if (!dg.ok) return fail(BRBD_ERR_RUNTIME, "hipSetDevice failed");
+  auto run = [&](int64_t Bc, const double* dq, int64_t l0, const double* dv, int64_t l1, double* dout, int64_t l2,
+                 hipStream_t st) -> int {
+    F4Args A{};
+    fill_f4(m, A, Bc);
+    A.q = dq; A.ldq = l0; A.v = dv; A.ldv = l1; A.out = dout; A.ldout = l2;
+    const int grid = f4_grid(m, m->max_waves_f4[1], integrate_kernel<1>, A.ntiles);
+    if (layout == BRBD_BATCH_MAJOR) hipLaunchKernelGGL(integrate_kernel<1>, dim3(grid), dim3(WAVE), 0, st, A);
+    else hipLaunchKernelGGL(integrate_kernel<0>, dim3(grid), dim3(WAVE), 0, st, A);
+    HIP_TRY(hipGetLastError());
+    return BRBD_OK;
+  };
+  if (memspace == BRBD_DEVICE) return run(B, q, ldq, v, ldv, qout, ldqout, (hipStream_t)stream);
+  const HostMat mats[3] = {{q, nullptr, ldq, F.nq, true, false}, {v, nullptr, ldv, F.nv, true, false},
+                           {nullptr, qout, ldqout, F.nq, false, true}};
+  return host_pipeline(m, B, layout, mats, 3, (hipStream_t)stream,
+                       [&](int64_t Bc, double** d, const int64_t* ld, hipStream_t st) -> int {
+                         return run(Bc, d[0], ld[0], d[1], ld[1], d[2], ld[2], st);
+                       });
+}
+
+int brbd_minverse(brbd_model* m, int64_t B, const double* q, int64_t ldq, double* Minv, int64_t ldminv, int layout,
+                  int memspace, void* stream) {
+  int rc = check_common(m, B, layout, memspace);
+  if (rc) return rc;
+  const FlatModel& F = m->flat;
+  const int64_t nn = (int64_t)F.nv * F.nv;
+  if ((rc = check_mat("q", q, ldq, F.nq, B, layout))) return rc;
+  if ((rc = check_mat("Minv", Minv, ldminv, nn, B, layout))) return rc;
+  if (!F.depth_first)
+    return fail(BRBD_ERR_UNSUPPORTED, "computeMinverse needs depth-first joint numbering (contiguous subtrees), as "
+                                      "pinocchio's Data::computeNvSubtree assumes");
+  if (B == 0) return BRBD_OK;
+  DevGuard dg(m->device);
+  if (!dg.ok) return fail(BRBD_ERR_RUNTIME, "hipSetDevice failed");
+  if (memspace == BRBD_DEVICE) return minverse_device(m, B, q, ldq, Minv, ldminv, 0, layout, (hipStream_t)stream);
+  const HostMat mats[2] = {{q, nullptr, ldq, F.nq, true, false}, {nullptr, Minv, ldminv, nn, false, true}};
+  return host_pipeline(m, B, layout, mats, 2, (hipStream_t)stream,
+                       [&](int64_t Bc, double** d, const int64_t* ld, hipStream_t st) -> int {
+                         return minverse_device(m, Bc, d[0], ld[0], d[1], ld[1], 0, layout, st);
+                       });
+}
+
+int brbd_aba_derivatives(brbd_model* m, int64_t B, const double* q, int64_t ldq, const double* v, int64_t ldv,
+                         const double* tau, int64_t ldtau, double* ddq_dq, int64_t lddq, double* ddq_dv, int64_t lddv,
+                         double* ddq_dtau, int64_t lddtau, double* ddq, int64_t ldddq, int layout, int memspace,
+                         void* stream) {
+  int rc = check_common(m, B, layout, memspace);
+  if (rc) return rc;
+  const FlatModel& F = m->flat;
+  const int64_t nn = (int64_t)F.nv * F.nv;
+  if ((rc = check_mat("q", q, ldq, F.nq, B, layout))) return rc;
+  if ((rc = check_mat("v", v, ldv, F.nv, B, layout))) return rc;
+  if ((rc = check_mat("tau", tau, ldtau, F.nv, B, layout))) return rc;
+  if ((rc = check_mat("ddq_dq", ddq_dq, lddq, nn, B, layout))) return rc;
+  if ((rc = check_mat("ddq_dv", ddq_dv, lddv, nn, B, layout))) return rc;
+  if ((rc = check_mat("ddq_dtau", ddq_dtau, lddtau, nn, B, layout))) return rc;
+  if (ddq && (rc = check_mat("ddq", ddq, ldddq, F.nv, B, layout))) return rc;
+  if (!F.depth_first)
+    return fail(BRBD_ERR_UNSUPPORTED, "computeABADerivatives needs depth-first joint numbering (contiguous subtrees)");
+  if (F.nv > 48) return fail(BRBD_ERR_UNSUPPORTED, "computeABADerivatives: models with nv > 48 are not supported yet");
+  if (B == 0) return BRBD_OK;
+  DevGuard dg(m->device);
+  if (!dg.ok) return fail(BRBD_ERR_RUNTIME, "hipSetDevice failed");
+  // aba-derivatives.hxx:381-454 with the engine's own building blocks: ddq = aba(q, v, tau); the RNEA
+  // partial derivatives at that acceleration (pass 4 of the reference); Minv, symmetrised (:449-450);
+  // the closing products (:452-453).  All on one stream, in order.
+  auto run = [&](int64_t Bc, const double* dq, int64_t l0, const double* dv, int64_t l1, const double* dt, int64_t l2,
+                 double* o1, int64_t lo1, double* o2, int64_t lo2, double* o3, int64_t lo3, double* acc, int64_t la,
+                 hipStream_t st) -> int {
+    int r = brbd_aba(m, Bc, dq, l0, dv, l1, dt, l2, acc, la, layout, BRBD_DEVICE, st);
+    if (r) return r;
+    const bool pz = m->prezeroed;
+    m->prezeroed = false;  // the products read every element of the two matrices
+    r = brbd_rnea_derivatives(m, Bc, dq, l0, dv, l1, acc, la, o1, lo1, o2, lo2, nullptr, 0, nullptr, 0, layout,
+                              BRBD_DEVICE, st);
+    m->prezeroed = pz;
+    if (r) return r;
+    if ((r = minverse_device(m, Bc, dq, l0, o3, lo3, 1, layout, st))) return r;
+    F4Args A{};
+    fill_f4(m, A, Bc);
+    A.out = o1; A.ldout = lo1; A.out2 = o2; A.ldout2 = lo2; A.minv = o3; A.ldminv = lo3;
+    const int grid = f4_grid(m, m->max_waves_f4[2], aba_deriv_product_kernel<1, 48>, A.ntiles);
+    if (layout == BRBD_BATCH_MAJOR) {
+      if (F.nv <= 24) hipLaunchKernelGGL((aba_deriv_product_kernel<1, 24>), dim3(grid), dim3(WAVE), 0, st, A);
+      else hipLaunchKernelGGL((aba_deriv_product_kernel<1, 48>), dim3(grid), dim3(WAVE), 0, st, A);
+    } else {
+      if (F.nv <= 24) hipLaunchKernelGGL((aba_deriv_product_kernel<0, 24>), dim3(grid), dim3(WAVE), 0, st, A);
+      else hipLaunchKernelGGL((aba_deriv_product_kernel<0, 48>), dim3(grid), dim3(WAVE), 0, st, A);
+    }
+    HIP_TRY(hipGetLastError());
+    return BRBD_OK;
+  };
+  if (memspace == BRBD_DEVICE) {
+    hipStream_t st = (hipStream_t)stream;
+    double* acc = ddq;
+    int64_t la = ldddq;
+    if (!acc) {  // the acceleration is needed anyway: a per-stream temporary
+      StreamCtx* ctx = get_ctx(m, st);
+      const int64_t ld = layout == BRBD_BATCH_MAJOR ? B : F.nv;
+      if ((rc = ensure_buf(&ctx->d_tmp, &ctx->tmp_doubles, (size_t)F.nv * (size_t)B, st))) return rc;
+      acc = ctx->d_tmp;
+      la = ld;
+    }
+    return run(B, q, ldq, v, ldv, tau, ldtau, ddq_dq, lddq, ddq_dv, lddv, ddq_dtau, lddtau, acc, la, st);
+  }
+  const HostMat mats[7] = {{q, nullptr, ldq, F.nq, true, false}, {v, nullptr, ldv, F.nv, true, false},
+                           {tau, nullptr, ldtau, F.nv, true, false}, {nullptr, ddq_dq, lddq, nn, false, true},
+                           {nullptr, ddq_dv, lddv, nn, false, true}, {nullptr, ddq_dtau, lddtau, nn, false, true},
+                           {nullptr, ddq, ldddq, F.nv, false, ddq != nullptr}};
+  return host_pipeline(m, B, layout, mats, 7, (hipStream_t)stream,
+                       [&](int64_t Bc, double** d, const int64_t* ld, hipStream_t st) -> int {
+                         return run(Bc, d[0], ld[0], d[1], ld[1], d[2], ld[2], d[3], ld[3], d[4], ld[4], d[5], ld[5],
+                                    d[6], ld[6], st);
+                       });
 }
 
 // ---- no-alloc variant ---------------------------------------------------------------------------

@@ -331,3 +331,49 @@ def computeRNEADerivatives(pool: ModelPool, q, v, a, want_tau: bool = False, dev
         dm.handle, a0.B, aq.ptr, aq.ld, av.ptr, av.ld, aa.ptr, aa.ld, d[0].ptr, d[0].ld, d[1].ptr, d[1].ld,
         d[2].ptr, d[2].ld, at.ptr if at else None, at.ld if at else 0, a0.layout, a0.space, _stream(a0)))
     return (outs[0], outs[1], outs[2], tau) if want_tau else tuple(outs)
+
+
+def integrate(pool: ModelPool, q, v, device: Optional[int] = None):
+    """Batched ``pin.integrate(model, q, v)`` (algorithm/joint-configuration.hxx): (nq, B)."""
+    m = pool.getModel(0)
+    aq = _describe(q, m.nq, "q")
+    av = _describe(v, m.nv, "v", aq.layout)
+    a0 = _same([aq, av])
+    out = _alloc_like(q, a0, m.nq)
+    ao = _describe(out, m.nq, "qout", aq.layout)
+    dm = pool.device_model(_device_of(a0, device))
+    capi.check(capi.lib().brbd_integrate(dm.handle, a0.B, aq.ptr, aq.ld, av.ptr, av.ld, ao.ptr, ao.ld, a0.layout,
+                                         a0.space, _stream(a0)))
+    return out
+
+
+def computeMinverse(pool: ModelPool, q, device: Optional[int] = None):
+    """Batched ``pin.computeMinverse(model, data, q)`` (algorithm/aba.hxx:841-877): (nv*nv, B), per
+    instance column-major; upper triangle like ``data.Minv``, strictly lower part zero."""
+    m = pool.getModel(0)
+    aq = _describe(q, m.nq, "q")
+    out = _alloc_like(q, aq, m.nv * m.nv)
+    ao = _describe(out, m.nv * m.nv, "Minv", aq.layout)
+    dm = pool.device_model(_device_of(aq, device))
+    capi.check(capi.lib().brbd_minverse(dm.handle, aq.B, aq.ptr, aq.ld, ao.ptr, ao.ld, aq.layout, aq.space, _stream(aq)))
+    return out
+
+
+def computeABADerivatives(pool: ModelPool, q, v, tau, want_ddq: bool = False, device: Optional[int] = None):
+    """Batched ``pin.computeABADerivatives(model, data, q, v, tau)`` (algorithm/aba-derivatives.hxx:381-454):
+    (ddq_dq, ddq_dv, ddq_dtau), each (nv*nv, B) column-major per instance, ddq_dtau = Minv full;
+    with ``want_ddq`` also ddq (nv, B)."""
+    m = pool.getModel(0)
+    aq = _describe(q, m.nq, "q")
+    av, at = _describe(v, m.nv, "v", aq.layout), _describe(tau, m.nv, "tau", aq.layout)
+    a0 = _same([aq, av, at])
+    nn = m.nv * m.nv
+    outs = [_alloc_like(q, a0, nn) for _ in range(3)]
+    d = [_describe(o, nn, "d", aq.layout) for o in outs]
+    acc = _alloc_like(q, a0, m.nv) if want_ddq else None
+    aa = _describe(acc, m.nv, "ddq", aq.layout) if want_ddq else None
+    dm = pool.device_model(_device_of(a0, device))
+    capi.check(capi.lib().brbd_aba_derivatives(
+        dm.handle, a0.B, aq.ptr, aq.ld, av.ptr, av.ld, at.ptr, at.ld, d[0].ptr, d[0].ld, d[1].ptr, d[1].ld,
+        d[2].ptr, d[2].ld, aa.ptr if aa else None, aa.ld if aa else 0, a0.layout, a0.space, _stream(a0)))
+    return (outs[0], outs[1], outs[2], acc) if want_ddq else tuple(outs)

@@ -41,6 +41,8 @@ def parse():
     p.add_argument("--model", default="simple_humanoid",
                    help="built-in model name, or the path of a URDF file (free-flyer root is added)")
     p.add_argument("--algo", default="rnea+aba", choices=["rnea+aba", "rnea", "aba"])
+    p.add_argument("--plugin", action="append", default=[],
+                   help="kernel plugin(s) built by `python -m pinocchio_amd.codegen.plugin` for this model")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
     return p.parse_args()
@@ -127,6 +129,8 @@ def main():
         dist = dist_
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    for path in args.plugin:
+        capi.load_compiled_kernels(path)
     model = load_model(args.model)
     do_rnea, do_aba = "rnea" in args.algo, "aba" in args.algo
     B = args.batch

@@ -263,6 +263,13 @@ int brbd_transpose_to_instance_major(int device, int64_t dof, int64_t B, const d
  * brbd_model_use_compiled(m, 0) forces the table-driven kernels (BRBD_DISABLE_COMPILED=1 does so
  * for every model).  No reference counterpart (closest: the CppADCodeGen path, out of scope). */
 const char* brbd_model_compiled_kernels(const brbd_model* m);
+/* Compiled kernels for a model that was NOT known when the library was built: the model compiler runs
+ * on any model (`python -m pinocchio_amd.codegen.plugin --urdf robot.urdf --out libbrbd_spec_robot.so`,
+ * a few minutes of hipcc) and links that model's kernels into a small shared library.  Loading it
+ * (before brbd_model_create; or list it in BRBD_COMPILED_PLUGINS=a.so:b.so) makes models with that
+ * signature run on them.  Returns the number of kernel sets added (>= 0) or a negative status
+ * (BRBD_ERR_INVALID_ARGUMENT: not loadable, not a plugin, or built against another kernel ABI). */
+int brbd_load_compiled_kernels(const char* path);
 int brbd_model_use_compiled(brbd_model* m, int enabled);
 
 /* Output contract of brbd_rnea_derivatives.  The reference requires the caller to zero the three

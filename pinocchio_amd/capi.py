@@ -37,7 +37,7 @@ SYMBOLS = (
     "brbd_rnea", "brbd_aba", "brbd_rnea_fext", "brbd_aba_fext", "brbd_fk_jacobians", "brbd_joint_jacobian", "brbd_rnea_derivatives",
     "brbd_transpose_to_batch_major", "brbd_transpose_to_instance_major",
     "brbd_set_timing", "brbd_kernel_time", "brbd_model_compiled_kernels", "brbd_model_use_compiled", "brbd_model_outputs_prezeroed", "brbd_model_canonical_form",
-    "brbd_integrate", "brbd_minverse", "brbd_aba_derivatives",
+    "brbd_load_compiled_kernels", "brbd_integrate", "brbd_minverse", "brbd_aba_derivatives",
     "brbd_aba_noalloc", "brbd_host_register", "brbd_host_unregister", "brbd_debug_oob_count",
 )
 
@@ -123,6 +123,8 @@ def lib():
     L.brbd_rnea.argtypes = [vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, ci, ci, vp]
     L.brbd_aba.restype = ci
     L.brbd_aba.argtypes = [vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, ci, ci, vp]
+    L.brbd_load_compiled_kernels.restype = ci
+    L.brbd_load_compiled_kernels.argtypes = [ctypes.c_char_p]
     L.brbd_integrate.restype = ci
     L.brbd_integrate.argtypes = [vp, i64, vp, i64, vp, i64, vp, i64, ci, ci, vp]
     L.brbd_minverse.restype = ci
@@ -166,6 +168,15 @@ def lib():
     L.brbd_kernel_time.argtypes = [vp, ci, ctypes.POINTER(i32), dp]
     _lib = L
     return L
+
+
+def load_compiled_kernels(path: str) -> int:
+    """Load a kernel plugin built by pinocchio_amd.codegen.plugin (include/brbd.h:
+    brbd_load_compiled_kernels); returns the number of kernel sets added."""
+    rc = lib().brbd_load_compiled_kernels(os.fsencode(path))
+    if rc < 0:
+        check(rc)
+    return rc
 
 
 def last_error() -> str:

@@ -6,6 +6,7 @@
 // There is NO CPU fallback in this library: without a HIP device every compute entry point
 // fails with BRBD_ERR_NO_DEVICE / BRBD_ERR_RUNTIME.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <cstdio>
 #include <cstdlib>
@@ -43,6 +44,12 @@ int fail(int code, const std::string& msg) {
       return fail(BRBD_ERR_RUNTIME, std::string(#expr) + ": " + hipGetErrorString(e_));     \
     }                                                                                       \
   } while (0)
+
+// Compiled kernels loaded at run time (brbd_load_compiled_kernels): entries of plugin libraries,
+// consulted after the ones this library was built with.
+std::mutex g_plugin_mu;
+std::vector<const brbd::SpecEntry*> g_plugin_entries;
+bool g_plugin_env_done = false;
 
 struct Ev {  // a hipEvent shared by the launches it delimits
   hipEvent_t e = nullptr;
@@ -496,6 +503,61 @@ int brbd_model_canonical_form(const brbd_model_desc* desc, int32_t* jtype, doubl
 
 static int resolve_scratch(brbd_model* m);  // (no-alloc variant, below)
 
+// Kernels compiled for a model AFTER this library was built: pinocchio_amd/codegen/plugin.py runs the
+// model compiler on any model (a URDF, a pinocchio::Model's tables) and links the kernels into a
+// small shared library; loading it here makes brbd_model_create select them for models with that
+// signature, exactly like the built-in ones.  Returns the number of entries added (>= 0) or a
+// negative status.
+int brbd_load_compiled_kernels(const char* path) {
+  if (!path || !*path) return fail(BRBD_ERR_INVALID_ARGUMENT, "path is NULL or empty");
+  void* h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+  if (!h) return fail(BRBD_ERR_INVALID_ARGUMENT, std::string("cannot load ") + path + ": " + dlerror());
+  typedef const SpecEntry* const* (*plugin_fn)(int*, int*);
+  plugin_fn fn = (plugin_fn)dlsym(h, "brbd_spec_plugin");
+  if (!fn) {
+    dlclose(h);
+    return fail(BRBD_ERR_INVALID_ARGUMENT, std::string(path) + " is not a brbd kernel plugin (no brbd_spec_plugin)");
+  }
+  int count = 0, info[3] = {0, 0, 0};
+  const SpecEntry* const* entries = fn(&count, info);
+  if (info[0] != BRBD_SPEC_ABI || info[1] != (int)sizeof(KArgs) || info[2] != (int)sizeof(SpecEntry)) {
+    dlclose(h);
+    return fail(BRBD_ERR_INVALID_ARGUMENT, std::string(path) + " was built against another layout of the kernel "
+                "arguments (ABI " + std::to_string(info[0]) + ", library " + std::to_string(BRBD_SPEC_ABI) + "): rebuild it");
+  }
+  int added = 0;
+  std::lock_guard<std::mutex> g(g_plugin_mu);
+  for (int k = 0; k < count; ++k) {
+    bool dup = false;
+    for (const SpecEntry* e : g_plugin_entries) dup = dup || std::string(e->signature) == entries[k]->signature;
+    if (!dup) {
+      g_plugin_entries.push_back(entries[k]);
+      ++added;
+    }
+  }
+  return added;  // (the library stays loaded for the life of the process: its kernels are in use)
+}
+
+static void load_plugins_from_env() {  // BRBD_COMPILED_PLUGINS = a.so:b.so, read once
+  {
+    std::lock_guard<std::mutex> g(g_plugin_mu);
+    if (g_plugin_env_done) return;
+    g_plugin_env_done = true;
+  }
+  const char* env = getenv("BRBD_COMPILED_PLUGINS");
+  if (!env) return;
+  std::string list(env);
+  size_t pos = 0;
+  while (pos <= list.size()) {
+    const size_t end = list.find(':', pos);
+    const std::string one = list.substr(pos, end == std::string::npos ? std::string::npos : end - pos);
+    if (!one.empty() && brbd_load_compiled_kernels(one.c_str()) < 0)
+      fprintf(stderr, "brbd: BRBD_COMPILED_PLUGINS: %s\n", g_err.c_str());
+    if (end == std::string::npos) break;
+    pos = end + 1;
+  }
+}
+
 int brbd_model_create(const brbd_model_desc* desc, int device, brbd_model** out) {
   if (!out) return fail(BRBD_ERR_INVALID_ARGUMENT, "out is NULL");
   *out = nullptr;
@@ -536,11 +598,17 @@ int brbd_model_create(const brbd_model_desc* desc, int device, brbd_model** out)
   if (e == hipSuccess)
     e = upload((void**)&m->d_nvsub, m->flat.nv_subtree.data(), m->flat.nv_subtree.size() * sizeof(int));
   if (e == hipSuccess) {
-    // model-compiled kernels: exact zero pattern first, then the dense kernels of the same tree
+    // model-compiled kernels: exact zero pattern first, then the dense kernels of the same tree;
+    // the kernels built into the library first, then those of plugins loaded at run time
+    load_plugins_from_env();
     const std::string exact = model_signature(m->flat, false), dense = model_signature(m->flat, true);
-    for (int pass = 0; pass < 2 && !m->spec; ++pass)
+    std::lock_guard<std::mutex> g(g_plugin_mu);
+    for (int pass = 0; pass < 2 && !m->spec; ++pass) {
       for (int k = 0; k < spec_entry_count && !m->spec; ++k)
         if ((pass == 0 ? exact : dense) == spec_entries[k]->signature) m->spec = spec_entries[k];
+      for (size_t k = 0; k < g_plugin_entries.size() && !m->spec; ++k)
+        if ((pass == 0 ? exact : dense) == g_plugin_entries[k]->signature) m->spec = g_plugin_entries[k];
+    }
     for (int a = 0; m->spec && a < 4 && e == hipSuccess; ++a) {
       const std::vector<double> ct = pack_constants(m->flat, m->spec->algo[a]);
       e = upload((void**)&m->d_ct[a], ct.data(), ct.size() * sizeof(double));

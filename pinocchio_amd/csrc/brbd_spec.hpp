@@ -34,6 +34,11 @@ struct SpecKernel {
 };
 enum : int { SF_R = 0, SF_T, SF_M, SF_C, SF_I, SF_ARM, SF_AXIS, SF_G };
 
+// Layout version of KArgs / SpecKernel / SpecEntry: kernels compiled separately (plugins built by
+// pinocchio_amd/codegen/plugin.py for models unknown when the library was built, loaded with
+// brbd_load_compiled_kernels) must agree with the library that launches them.
+#define BRBD_SPEC_ABI 3
+
 struct SpecEntry {
   const char* name;
   const char* signature;  // tree + joint kinds + 0/1/-1 pattern of the constants (codegen/joints.py)

@@ -11,8 +11,11 @@
 // (fields of SURVEY 8a row a13; joint kind from shortname(), e.g. joint-revolute.hpp:848-851).
 #pragma once
 #include <cstring>
+#include <exception>
+#include <memory>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "brbd.h"
@@ -121,6 +124,81 @@ void abaInParallel(const size_t num_threads, ModelPool& pool, const ConfigPool& 
                         (int64_t)v.outerStride(), tau.data(), (int64_t)tau.outerStride(),
                         const_cast<double*>(a.data()), (int64_t)a.outerStride(), BRBD_INSTANCE_MAJOR,
                         BRBD_HOST, nullptr));
+}
+
+// ---- one process, several GPUs ---------------------------------------------------------------------
+// The static column split of the reference's OpenMP loop (parallel/rnea.hpp:74-82) with one host
+// thread + one device model per GPU: slice k = columns [k B / G, (k + 1) B / G) runs on devices[k].
+// No collective and no peer copy: every slice is staged by its own device.
+class MultiDevicePool {
+ public:
+  MultiDevicePool(const ModelDesc& model, size_t pool_size, const std::vector<int>& devices) : size_(pool_size) {
+    if (devices.empty()) throw std::invalid_argument("devices must name at least one GPU");
+    for (int d : devices) pools_.emplace_back(new ModelPool(model, pool_size, d));
+  }
+  size_t size() const { return size_; }
+  size_t devices() const { return pools_.size(); }
+  ModelPool& on(size_t k) { return *pools_[k]; }
+
+ private:
+  size_t size_;
+  std::vector<std::unique_ptr<ModelPool>> pools_;
+};
+
+namespace detail {
+struct ColumnSlice {  // a block of columns of a column-major matrix: same outerStride, shifted data
+  long r, c, ld;
+  const double* p;
+  long rows() const { return r; }
+  long cols() const { return c; }
+  long outerStride() const { return ld; }
+  const double* data() const { return p; }
+};
+template <class Mat>
+ColumnSlice columns(const Mat& m, long lo, long hi) {
+  return ColumnSlice{(long)m.rows(), hi - lo, (long)m.outerStride(), m.data() + lo * (long)m.outerStride()};
+}
+template <class F>
+void on_every_device(MultiDevicePool& pool, long B, F f) {
+  const long G = (long)pool.devices();
+  std::vector<std::thread> threads;
+  std::vector<std::exception_ptr> errs((size_t)G);
+  for (long k = 0; k < G; ++k)
+    threads.emplace_back([&, k] {
+      try {
+        const long lo = k * B / G, hi = (k + 1) * B / G;
+        if (hi > lo) f(pool.on((size_t)k), lo, hi);
+      } catch (...) {
+        errs[(size_t)k] = std::current_exception();
+      }
+    });
+  for (auto& t : threads) t.join();
+  for (auto& e : errs)
+    if (e) std::rethrow_exception(e);
+}
+}  // namespace detail
+
+template <class ConfigPool, class Tangent1, class Tangent2, class Tangent3>
+void rneaInParallel(const size_t num_threads, MultiDevicePool& pool, const ConfigPool& q, const Tangent1& v,
+                    const Tangent2& a, const Tangent3& tau) {
+  detail::check(pool.size() > 0, "The pool should have at least one element");
+  detail::check(num_threads <= pool.size(), "The pool is too small");
+  detail::check(q.cols() == v.cols() && q.cols() == a.cols() && q.cols() == tau.cols(), "column mismatch");
+  detail::on_every_device(pool, (long)q.cols(), [&](ModelPool& p, long lo, long hi) {
+    rneaInParallel(num_threads, p, detail::columns(q, lo, hi), detail::columns(v, lo, hi), detail::columns(a, lo, hi),
+                   detail::columns(tau, lo, hi));
+  });
+}
+template <class ConfigPool, class Tangent1, class Tangent2, class Tangent3>
+void abaInParallel(const size_t num_threads, MultiDevicePool& pool, const ConfigPool& q, const Tangent1& v,
+                   const Tangent2& tau, const Tangent3& a) {
+  detail::check(pool.size() > 0, "The pool should have at least one element");
+  detail::check(num_threads <= pool.size(), "The pool is too small");
+  detail::check(q.cols() == v.cols() && q.cols() == a.cols() && q.cols() == tau.cols(), "column mismatch");
+  detail::on_every_device(pool, (long)q.cols(), [&](ModelPool& p, long lo, long hi) {
+    abaInParallel(num_threads, p, detail::columns(q, lo, hi), detail::columns(v, lo, hi), detail::columns(tau, lo, hi),
+                  detail::columns(a, lo, hi));
+  });
 }
 
 // Batched rnea(model, data, q, v, a, fext) / aba(model, data, q, v, tau, fext) (algorithm/rnea.hxx:171-219,

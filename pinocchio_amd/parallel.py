@@ -83,11 +83,14 @@ class ModelPool:
             d.close()
         self._dev = {}
 
-    def device_model(self, device: int = 0) -> capi.DeviceModel:
-        d = self._dev.get(device)
+    def device_model(self, device: int = 0, replica: int = 0) -> capi.DeviceModel:
+        """The flattened model on GPU `device` (`replica` > 0: a further handle on the same GPU, for
+        callers that drive one GPU from several host threads)."""
+        key = device if replica == 0 else (device, replica)
+        d = self._dev.get(key)
         if d is None:
             d = capi.DeviceModel(self._model, device)
-            self._dev[device] = d
+            self._dev[key] = d
         return d
 
 
@@ -377,3 +380,63 @@ def computeABADerivatives(pool: ModelPool, q, v, tau, want_ddq: bool = False, de
         dm.handle, a0.B, aq.ptr, aq.ld, av.ptr, av.ld, at.ptr, at.ld, d[0].ptr, d[0].ld, d[1].ptr, d[1].ld,
         d[2].ptr, d[2].ld, aa.ptr if aa else None, aa.ld if aa else 0, a0.layout, a0.space, _stream(a0)))
     return (outs[0], outs[1], outs[2], acc) if want_ddq else tuple(outs)
+
+
+# --------------------------------------------------------------------------------------------
+# One process, several GPUs: the static column split of the reference's OpenMP loop
+# (algorithm/parallel/rnea.hpp:74-82: thread t gets a contiguous block of columns) with one host
+# thread + one device model + one stream context per GPU instead of one thread per core.  Host
+# matrices only (each slice is staged by its own device's pipeline); no collective, no peer copies.
+def _sharded(fn_name, pool: ModelPool, devices, mats, rows, out_index):
+    import threading
+    from .launch import column_slice
+    m = pool.getModel(0)
+    descs = [_describe(x, r, n) for x, r, n in zip(mats, rows, ("q", "v", "x", "out"))]
+    a0 = _same(descs)
+    if a0.space != capi.HOST:
+        raise BrbdInvalidArgument("the multi-device helpers take host matrices (device tensors already live on one GPU)")
+    G = len(devices)
+    if G < 1:
+        raise BrbdInvalidArgument("devices must name at least one GPU")
+    handles = [pool.device_model(d, replica=k) for k, d in enumerate(devices)]
+    fn = getattr(capi.lib(), fn_name)
+    errors = []
+
+    def work(k):
+        lo, hi = column_slice(a0.B, k, G)
+        if hi <= lo:
+            return
+        # slice k of every matrix: same leading dimension, shifted base pointer
+        ptrs = [d.ptr + 8 * (lo * d.ld if d.layout == capi.INSTANCE_MAJOR else lo) for d in descs]
+        rc = fn(handles[k].handle, hi - lo, ptrs[0], descs[0].ld, ptrs[1], descs[1].ld, ptrs[2], descs[2].ld,
+                ptrs[3], descs[3].ld, a0.layout, capi.HOST, None)
+        if rc != capi.BRBD_OK:
+            errors.append((rc, capi.last_error()))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(G)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise capi.BrbdRuntimeError("a device slice failed: %r" % (errors[0],))
+    return descs[out_index].keep
+
+
+def rneaInParallelOnDevices(num_threads: int, pool: ModelPool, q, v, a, devices, tau=None):
+    """rneaInParallel with the batch split into contiguous column slices, slice k on GPU devices[k]
+    (one host thread per GPU, all slices in flight at once)."""
+    _pool_checks(num_threads, pool)
+    m = pool.getModel(0)
+    aq = _describe(q, m.nq, "q")
+    out = tau if tau is not None else _alloc_like(q, aq, m.nv)
+    return _sharded("brbd_rnea", pool, devices, (q, v, a, out), (m.nq, m.nv, m.nv, m.nv), 3)
+
+
+def abaInParallelOnDevices(num_threads: int, pool: ModelPool, q, v, tau, devices, a=None):
+    """abaInParallel with slice k of the columns on GPU devices[k]."""
+    _pool_checks(num_threads, pool)
+    m = pool.getModel(0)
+    aq = _describe(q, m.nq, "q")
+    out = a if a is not None else _alloc_like(q, aq, m.nv)
+    return _sharded("brbd_aba", pool, devices, (q, v, tau, out), (m.nq, m.nv, m.nv, m.nv), 3)

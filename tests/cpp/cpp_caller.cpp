@@ -109,6 +109,16 @@ int main(int argc, char** argv) {
         for (long i = nv; i < vt.ld; ++i)
           if (st[(size_t)(j * vt.ld + i)] != -1.5e300) { ++fails; std::fprintf(stderr, "padding overwritten at column %ld\n", j); i = vt.ld; }
     }
+    // one process, several devices: the column split over a MultiDevicePool (here: two handles on
+    // GPU 0, one host thread each) gives the same numbers as the single-device call
+    {
+      brbd::MultiDevicePool multi(m, 4, {0, 0});
+      Mat tau2(nv, B, NAN), ddq2(nv, B, NAN);
+      brbd::rneaInParallel(2, multi, q, v, a, tau2);
+      brbd::abaInParallel(2, multi, q, v, tau2, ddq2);
+      for (size_t k = 0; k < tau.d.size(); ++k)
+        if (tau2.d[k] != tau.d[k] || ddq2.d[k] != ddq.d[k]) { ++fails; std::fprintf(stderr, "multi-device result differs at %zu\n", k); break; }
+    }
     // argument checks still throw std::invalid_argument before any device work
     try {
       brbd::rneaInParallel(5, pool, q, v, a, tau);

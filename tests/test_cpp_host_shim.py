@@ -11,7 +11,7 @@ def test_cpp_host_shim(tmp_path):
     lib = os.path.join(ROOT, "pinocchio_amd")
     subprocess.check_call(["g++", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "cpp", "host_shim_check.cpp"), "-o", str(exe),
-                           "-L" + lib, "-lbrbd_hip", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib"])
+                           "-L" + lib, "-lbrbd_hip", "-pthread", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib"])
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "ok" in r.stdout

@@ -34,7 +34,7 @@ def test_cpp_caller_reproduces_reference_and_golden_values(tmp_path):
     lib = os.path.join(ROOT, "pinocchio_amd")
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "cpp", "cpp_caller.cpp"), "-o", str(exe),
-                           "-L" + lib, "-lbrbd_hip", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib"])
+                           "-L" + lib, "-lbrbd_hip", "-pthread", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib"])
     # (1) unittest/value.cpp: gravity -9.8, five columns with their own tolerances
     ref = json.load(open(os.path.join(GOLD, "reference_value_cpp.json")))["simple_humanoid"]
     m = S.simple_humanoid()

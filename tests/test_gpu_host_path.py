@@ -195,3 +195,24 @@ def test_permuted_dof_order_on_a_registered_tree():
     pool = parallel.ModelPool(model, 1)
     assert pool.device_model(0).compiled_kernels() == "arm7_p"
     pool.release()
+
+
+@pytest.mark.parametrize("order", ["F", "C"])
+def test_one_process_several_devices_column_split(order):
+    """rneaInParallelOnDevices / abaInParallelOnDevices: slice k of the columns on devices[k], one host
+    thread per device (here three handles on GPU 0; on an 8-GPU node devices=range(8)).  Same numbers
+    as the single-device call, ragged split included."""
+    model = S.quadruped()
+    pool = parallel.ModelPool(model, 4)
+    B = 10007
+    q, v, a = inputs(model, B, 77)
+    qq, vv, aa = (np.asarray(x, order=order) for x in (q, v, a))
+    tau1 = parallel.rneaInParallel(1, pool, qq, vv, aa)
+    tau3 = parallel.rneaInParallelOnDevices(3, pool, qq, vv, aa, devices=[0, 0, 0])
+    assert np.array_equal(tau1, tau3)
+    ddq3 = parallel.abaInParallelOnDevices(3, pool, qq, vv, tau3, devices=[0, 0, 0])
+    assert np.array_equal(ddq3, parallel.abaInParallel(1, pool, qq, vv, tau1))
+    assert rel_err_cols(ddq3, a).max() < TOL_ABA
+    with pytest.raises(capi.BrbdInvalidArgument):
+        parallel.rneaInParallelOnDevices(1, pool, qq, vv, aa, devices=[])
+    pool.release()

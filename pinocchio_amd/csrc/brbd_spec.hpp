@@ -161,33 +161,44 @@ struct SpecStage {
   double* rows;  // this wave's global staging rows ([row][64 lanes]), MODE 1
   unsigned rows_bytes;
 };
-template <int N, int AUX, typename Sink>
-DI void spec_stage_load(const double* base, unsigned bytes, const SpecStage& sc, Sink&& sink) {
+// Two phases, so that the loads of ALL staged matrices are in flight before the first one is waited
+// for (one exposed HBM latency per kernel instead of one per matrix): issue() = the N coalesced
+// loads of the tile's flat run; commit() = through LDS, each lane receives its own N values.
+template <int N, int AUX>
+DI void spec_stage_issue(const double* base, unsigned bytes, const SpecStage& sc, double* x) {
   const __amdgpu_buffer_rsrc_t r = spec_rsrc(base, bytes);
   // flat run of the tile: element j * 64 + lane; past the end of the batch the range check returns 0
   const unsigned t0 = (unsigned)sc.tile * (unsigned)(WAVE * N * 8) + (unsigned)sc.lane * 8u;
-  double x[N];
 #pragma unroll
   for (int j = 0; j < N; ++j)
     x[j] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, t0, (unsigned)(j * WAVE * 8), AUX));
+}
+template <int N, typename Sink>
+DI void spec_stage_commit(const SpecStage& sc, const double* x, Sink&& sink) {
   __syncthreads();  // (one wave per workgroup: orders the LDS traffic, no cross-wave wait)
 #pragma unroll
   for (int j = 0; j < N; ++j) sc.lds[j * WAVE + sc.lane] = x[j];
   __syncthreads();
 #pragma unroll
   for (int d = 0; d < N; ++d) sink(d, sc.lds[sc.lane * N + d]);
-  __syncthreads();
 }
 template <int LAYOUT, int AUX, int N, int MODE>
 struct SpecIn : SpecMat<LAYOUT, AUX> {
   DI SpecIn(const double* base, unsigned bytes, unsigned ld8, int64_t b, unsigned long long* oob_, const SpecStage&, int)
       : SpecMat<LAYOUT, AUX>(base, bytes, ld8, b, oob_) {}
+  DI void commit(const SpecStage&) {}
 };
 template <int AUX, int N>
 struct SpecIn<2, AUX, N, 0> {  // staged into registers
-  double r[N > 0 ? N : 1];
+  double r[N > 0 ? N : 1];    // (issue: the lane's share of the flat run; after commit: its own row)
   DI SpecIn(const double* base, unsigned bytes, unsigned, int64_t, unsigned long long*, const SpecStage& sc, int) {
-    spec_stage_load<N, AUX>(base, bytes, sc, [&](int d, double x) { r[d] = x; });
+    spec_stage_issue<N, AUX>(base, bytes, sc, r);
+  }
+  DI void commit(const SpecStage& sc) {
+    double x[N > 0 ? N : 1];
+#pragma unroll
+    for (int j = 0; j < N; ++j) x[j] = r[j];
+    spec_stage_commit<N>(sc, x, [&](int d, double y) { r[d] = y; });
   }
   DI double get(int d, unsigned) const { return r[d]; }
 };
@@ -197,9 +208,13 @@ struct SpecIn<2, AUX, N, 1> {  // staged into the wave's global rows row0 .. row
   unsigned voff, nbytes;
   int row0;
   unsigned long long* oob;
+  double pend[N > 0 ? N : 1];
   DI SpecIn(const double* base, unsigned bytes, unsigned, int64_t, unsigned long long* oob_, const SpecStage& sc, int row0_)
       : rr(spec_rsrc(sc.rows, sc.rows_bytes)), voff((unsigned)sc.lane * 8u), nbytes(sc.rows_bytes), row0(row0_), oob(oob_) {
-    spec_stage_load<N, AUX>(base, bytes, sc, [&](int d, double x) {
+    spec_stage_issue<N, AUX>(base, bytes, sc, pend);
+  }
+  DI void commit(const SpecStage& sc) {
+    spec_stage_commit<N>(sc, pend, [&](int d, double x) {
       SPEC_CHECK(oob, voff + (unsigned)((row0 + d) * WAVE * 8), 8u, nbytes, 7);
       __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, x), rr, voff, (unsigned)((row0 + d) * WAVE * 8), 0);
     });
@@ -346,9 +361,11 @@ DI void spec_sincos(double x, double& so, double& co) {
   const SpecStage sc{tile, lane, reinterpret_cast<double*>(lds_area),                                \
                      A.ws + (int64_t)blockIdx.x * A.ws_stride + (int64_t)SPEC_GLB * WAVE,            \
                      (unsigned)((SPEC_NQ + SPEC_NV + SPEC_NX) * WAVE * 8)};                           \
-  const SpecIn<LAYOUT, SPEC_IN_AUX, SPEC_NQ, SPEC_STAGE_MODE> mq(A.q, A.nb[0], ldq8, inst, A.oob, sc, 0);          \
-  const SpecIn<LAYOUT, SPEC_IN_AUX, SPEC_NV, SPEC_STAGE_MODE> mv(A.v, A.nb[1], ldv8, inst, A.oob, sc, SPEC_NQ);    \
-  const SpecIn<LAYOUT, SPEC_IN_AUX, SPEC_NX, SPEC_STAGE_MODE> mx(A.a, A.nb[2], ldx8, inst, A.oob, sc, SPEC_NQ + SPEC_NV); \
+  SpecIn<LAYOUT, SPEC_IN_AUX, SPEC_NQ, SPEC_STAGE_MODE> mq(A.q, A.nb[0], ldq8, inst, A.oob, sc, 0);                \
+  SpecIn<LAYOUT, SPEC_IN_AUX, SPEC_NV, SPEC_STAGE_MODE> mv(A.v, A.nb[1], ldv8, inst, A.oob, sc, SPEC_NQ);          \
+  SpecIn<LAYOUT, SPEC_IN_AUX, SPEC_NX, SPEC_STAGE_MODE> mx(A.a, A.nb[2], ldx8, inst, A.oob, sc, SPEC_NQ + SPEC_NV); \
+  mq.commit(sc); mv.commit(sc); mx.commit(sc); /* layout 2: all loads were issued above */           \
+  if ((LAYOUT) == 2) __syncthreads();                                                                \
   const SpecOut<LAYOUT, SPEC_OUT_AUX, SPEC_NO> mo(A.out, A.nb[3], ldo8, inst, A.oob);                \
   const SpecMat<LAY_, SPEC_OUT_AUX> mo2(A.out2, A.nb[4], ldo28, inst, A.oob);                        \
   const SpecMat<LAY_, SPEC_OUT_AUX> mo3(A.out3, A.nb[5], ldo38, inst, A.oob);                        \

@@ -22,7 +22,7 @@ def timed(dm, algo, fn, reps):
     n, ms = dm.kernel_time(algo)
     return ms / max(n, 1) * 1e-3 * (n / reps)   # seconds per call (chunked launches summed)
 
-which = sys.argv[1:] or ["fkjac", "aba", "rnea", "deriv", "fext", "jjac"]
+which = sys.argv[1:] or ["fkjac", "aba", "rnea", "deriv", "fext", "jjac", "f4", "layouts"]
 if "fkjac" in which:
     m = S.arm7(); B = 1 << 20; pool = parallel.ModelPool(m, 1); dm = pool.device_model(0)
     q, _, _ = inputs(m, B)
@@ -81,4 +81,42 @@ if "jjac" in which:   # arm7 end-effector Jacobian, LOCAL_WORLD_ALIGNED
     byts = (m.nq + 6 * m.nv) * 8 * B
     print(json.dumps({"config": "arm7 getJointJacobian(last joint, LOCAL_WORLD_ALIGNED) B=1048576 (wall time per call)",
                       "s_per_call": t, "evals_per_s": B / t, "GBps_algorithmic": byts / t / 1e9}))
+    pool.release()
+
+def wall(fn, reps):
+    import time
+    for _ in range(3): fn()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(reps): fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+if "f4" in which:   # rollout support, quadruped B = 262144 and humanoid B = 65536
+    for m, B in ((S.quadruped(), 1 << 18), (S.simple_humanoid(), 1 << 16)):
+        pool = parallel.ModelPool(m, 1)
+        q, v, a = inputs(m, B)
+        t = wall(lambda: parallel.integrate(pool, q, v), 20)
+        print(json.dumps({"config": f"{m.name} integrate B={B} (wall time per call)", "s_per_call": t, "evals_per_s": B / t,
+                          "GBps_algorithmic": (2 * m.nq + m.nv) * 8 * B / t / 1e9}))
+        t = wall(lambda: parallel.computeMinverse(pool, q), 5)
+        print(json.dumps({"config": f"{m.name} computeMinverse B={B} (wall time per call)", "s_per_call": t, "evals_per_s": B / t,
+                          "GBps_algorithmic": (m.nq + m.nv * m.nv) * 8 * B / t / 1e9}))
+        t = wall(lambda: parallel.computeABADerivatives(pool, q, v, a), 5)
+        print(json.dumps({"config": f"{m.name} computeABADerivatives B={B} (wall time per call)", "s_per_call": t, "evals_per_s": B / t,
+                          "GBps_algorithmic": (m.nq + 2 * m.nv + 3 * m.nv * m.nv) * 8 * B / t / 1e9}))
+        pool.release()
+if "layouts" in which:   # the reference's own layout, device resident, against BATCH_MAJOR (humanoid, kernel times)
+    m = S.simple_humanoid(); pool = parallel.ModelPool(m, 1); dm = pool.device_model(0)
+    for B in (1 << 14, 1 << 16, 1 << 20):
+        q, v, a = inputs(m, B)
+        qi, vi, ai = (x.t().contiguous().t() for x in (q, v, a))
+        tau, taui = torch.empty_like(a), torch.empty_like(ai.t()).t()
+        ddq, ddqi = torch.empty_like(a), torch.empty_like(ai.t()).t()
+        reps = 40 if B < (1 << 20) else 5
+        r = {"config": f"simple_humanoid kernel time by layout B={B}"}
+        r["rnea_batch_major_us"] = timed(dm, capi.ALGO_RNEA, lambda: parallel.rneaInParallel(1, pool, q, v, a, tau), reps) * 1e6
+        r["aba_batch_major_us"] = timed(dm, capi.ALGO_ABA, lambda: parallel.abaInParallel(1, pool, q, v, tau, ddq), reps) * 1e6
+        r["rnea_instance_major_us"] = timed(dm, capi.ALGO_RNEA, lambda: parallel.rneaInParallel(1, pool, qi, vi, ai, taui), reps) * 1e6
+        r["aba_instance_major_us"] = timed(dm, capi.ALGO_ABA, lambda: parallel.abaInParallel(1, pool, qi, vi, taui, ddqi), reps) * 1e6
+        print(json.dumps(r))
     pool.release()

@@ -73,6 +73,8 @@ struct StreamCtx {
   size_t stage_doubles = 0;
   double* d_tmp = nullptr;    // brbd_aba_derivatives: the acceleration when the caller does not want it
   size_t tmp_doubles = 0;
+  double* d_xp = nullptr;     // via_batch_major: batch-major copies of one column chunk
+  size_t xp_doubles = 0;
   hipStream_t pipe[2] = {nullptr, nullptr};  // internal streams of the host-memspace pipeline
   hipEvent_t ev_in = nullptr, ev_done[2] = {nullptr, nullptr};
 };
@@ -191,6 +193,7 @@ void free_ctx(StreamCtx& c) {
   if (c.d_ws) (void)hipFree(c.d_ws);
   if (c.d_stage) (void)hipFree(c.d_stage);
   if (c.d_tmp) (void)hipFree(c.d_tmp);
+  if (c.d_xp) (void)hipFree(c.d_xp);
   for (int k = 0; k < 2; ++k) {
     if (c.ev_done[k]) (void)hipEventDestroy(c.ev_done[k]);
     if (c.pipe[k]) (void)hipStreamDestroy(c.pipe[k]);
@@ -296,7 +299,8 @@ struct FixedWs {
 };
 
 // One algorithm launch on device pointers.
-int launch_algo(brbd_model* m, int algo, KArgs& A, int layout, hipStream_t stream, const FixedWs* fixed = nullptr) {
+int launch_algo(brbd_model* m, int algo, KArgs& A, int layout, hipStream_t stream, const FixedWs* fixed = nullptr,
+                int prezeroed = -1 /* -1: the handle's setting */) {
   const FlatModel& F = m->flat;
   if (A.B == 0) return BRBD_OK;
   int per_lane = 0;
@@ -312,7 +316,7 @@ int launch_algo(brbd_model* m, int algo, KArgs& A, int layout, hipStream_t strea
   int variant = 0, klayout = layout;
   if (sk) {
     if (algo == BRBD_ALGO_FK_JAC) variant = (A.out ? 1 : 0) | (A.out2 ? 2 : 0);
-    else if (algo == BRBD_ALGO_RNEA_DERIV) variant = m->prezeroed ? 1 : 0;
+    else if (algo == BRBD_ALGO_RNEA_DERIV) variant = (prezeroed < 0 ? m->prezeroed : prezeroed != 0) ? 1 : 0;
     else variant = A.fext ? 1 : 0;  // rnea / aba: kernel variant with external forces
     // buffer ranges: every matrix must span less than 4 GiB (32-bit byte offsets)
     const int64_t nn = (int64_t)F.nv * F.nv;
@@ -691,6 +695,69 @@ int64_t brbd_workspace_bytes(const brbd_model* m, int algo, int64_t B) {
 extern "C++" {
 namespace {
 
+// ---- INSTANCE_MAJOR device matrices through the BATCH_MAJOR kernels -------------------------------
+// An output-bound algorithm (the RNEA derivatives: 3 nv x nv matrices per instance) writes its
+// results one element at a time; in the reference's own layout that is, per store, 64 lanes
+// hitting 64 different cache lines several KiB apart, and the memory system merges almost none of
+// it (measured: 7x the BATCH_MAJOR time).  Instead: a column chunk of the inputs is transposed
+// into per-stream batch-major copies, the BATCH_MAJOR kernel runs on those, and the outputs are
+// transposed back with 512-byte runs on both sides (xpose64_kernel).  Chunks of up to 1 GiB of
+// copies (BRBD_VIA_BM_CHUNK = instances per chunk overrides): measured, larger chunks are faster --
+// the launches of a small chunk do not fill the device.  Same kernels, same arithmetic, same bits.
+struct XpMat {
+  const double* in;  // device matrix read by the algorithm (NULL: not an input)
+  double* out;       // device matrix written by it (NULL: not an output)
+  int64_t ld, dof;
+};
+
+bool via_bm_enabled() {
+  static const bool off = getenv("BRBD_DISABLE_VIA_BM") && getenv("BRBD_DISABLE_VIA_BM")[0] == '1';
+  return !off;
+}
+
+template <typename Launch>
+int via_batch_major(brbd_model* m, int64_t B, const XpMat* mats, int nm, hipStream_t st, Launch launch) {
+  int64_t tot = 0;
+  for (int i = 0; i < nm; ++i) tot += mats[i].dof;
+  static const int64_t forced = getenv("BRBD_VIA_BM_CHUNK") ? atoll(getenv("BRBD_VIA_BM_CHUNK")) : 0;
+  int64_t C = forced > 0 ? forced : (int64_t)((1024u << 20) / 8) / (tot > 0 ? tot : 1);  // 1 GiB of copies
+  C = (C / WAVE) * WAVE;
+  if (C < 1024) C = 1024;
+  {  // equal chunks: a short last one would leave most of the device idle for three launches
+    const int64_t n = (B + C - 1) / C;
+    C = (((B + n - 1) / n + WAVE - 1) / WAVE) * WAVE;
+  }
+  StreamCtx* ctx = get_ctx(m, st);
+  int rc = ensure_buf(&ctx->d_xp, &ctx->xp_doubles, (size_t)C * (size_t)tot, st);
+  if (rc) return rc;
+  double* d[8];
+  int64_t ld[8];
+  {
+    size_t off = 0;
+    for (int i = 0; i < nm; ++i) {
+      d[i] = mats[i].dof ? ctx->d_xp + off : nullptr;
+      ld[i] = C;
+      off += (size_t)mats[i].dof * (size_t)C;
+    }
+  }
+  for (int64_t c0 = 0; c0 < B; c0 += C) {
+    const int64_t Bc = B - c0 < C ? B - c0 : C;
+    const unsigned gx = (unsigned)((Bc + 63) / 64);
+    for (int i = 0; i < nm; ++i)
+      if (mats[i].in && mats[i].dof)
+        hipLaunchKernelGGL(xpose64_kernel<1>, dim3(gx), dim3(256), 0, st,
+                           mats[i].in + c0 * mats[i].ld, mats[i].ld, d[i], C, mats[i].dof, Bc);
+    HIP_TRY(hipGetLastError());
+    if ((rc = launch(Bc, d, ld, st))) return rc;
+    for (int i = 0; i < nm; ++i)
+      if (mats[i].out && mats[i].dof)
+        hipLaunchKernelGGL(xpose64_kernel<0>, dim3(gx), dim3(256), 0, st, d[i], C,
+                           mats[i].out + c0 * mats[i].ld, mats[i].ld, mats[i].dof, Bc);
+    HIP_TRY(hipGetLastError());
+  }
+  return BRBD_OK;
+}
+
 struct HostMat {
   const double* src;  // host matrix (uploaded when `up`)
   double* dst;        // same matrix as an output (downloaded when `down`), else NULL
@@ -1010,14 +1077,14 @@ int brbd_rnea_derivatives(brbd_model* m, int64_t B, const double* q, int64_t ldq
   hipStream_t s = (hipStream_t)stream;
   // in[0..2] = q, v, a; out[0..3] = dtau_dq, dtau_dv, dtau_da, tau (the last two may be NULL)
   auto run = [&](int64_t Bc, const double* const* in, const int64_t* ldi, double* const* out, const int64_t* ldo,
-                 hipStream_t st) -> int {
+                 hipStream_t st, int layout, int pz) -> int {
     if (m->spec && m->use_spec) {  // model-compiled kernel (codegen/deriv.py), when registered
       KArgs A{};
       fill_common(m, A, Bc);
       A.q = in[0]; A.ldq = ldi[0]; A.v = in[1]; A.ldv = ldi[1]; A.a = in[2]; A.lda = ldi[2];
       A.out = out[0]; A.ldout = ldo[0]; A.out2 = out[1]; A.ldout2 = ldo[1]; A.out3 = out[2]; A.ldout3 = ldo[2];
       A.out4 = out[3]; A.ldout4 = ldo[3];
-      const int r = launch_algo(m, BRBD_ALGO_RNEA_DERIV, A, layout, st);
+      const int r = launch_algo(m, BRBD_ALGO_RNEA_DERIV, A, layout, st, nullptr, pz);
       if (r <= 0) return r;  // 1 = no compiled kernel applies
     }
     DerivArgs D{};
@@ -1051,7 +1118,19 @@ int brbd_rnea_derivatives(brbd_model* m, int64_t B, const double* q, int64_t ldq
     const int64_t ldi[3] = {ldq, ldv, lda};
     double* out[4] = {dtau_dq, dtau_dv, dtau_da, tau};
     const int64_t ldo[4] = {lddq, lddv, ldda, ldtau};
-    return run(B, in, ldi, out, ldo, s);
+    if (layout == BRBD_INSTANCE_MAJOR && B >= 4096 && via_bm_enabled()) {
+      // the reference's own layout: through the BATCH_MAJOR kernel (see via_batch_major).  The
+      // copies are not pre-zeroed, so the kernel variant that writes the structural zeros runs.
+      const XpMat mats[7] = {{q, nullptr, ldq, F.nq}, {v, nullptr, ldv, F.nv}, {a, nullptr, lda, F.nv},
+                             {nullptr, dtau_dq, lddq, nn}, {nullptr, dtau_dv, lddv, nn},
+                             {nullptr, dtau_da, ldda, dtau_da ? nn : 0}, {nullptr, tau, ldtau, tau ? F.nv : 0}};
+      return via_batch_major(m, B, mats, 7, s, [&](int64_t Bc, double** d, const int64_t* ld, hipStream_t st) -> int {
+        const double* bin[3] = {d[0], d[1], d[2]};
+        double* bout[4] = {d[3], d[4], dtau_da ? d[5] : nullptr, tau ? d[6] : nullptr};
+        return run(Bc, bin, ld, bout, ld + 3, st, BRBD_BATCH_MAJOR, 0);
+      });
+    }
+    return run(B, in, ldi, out, ldo, s, layout, -1);
   }
   // under the prezeroed contract the kernel leaves the structural zeros alone: the caller's zeros
   // must be on the device too, so those outputs are uploaded as well
@@ -1064,7 +1143,7 @@ int brbd_rnea_derivatives(brbd_model* m, int64_t B, const double* q, int64_t ldq
   return host_pipeline(m, B, layout, mats, 7, s, [&](int64_t Bc, double** d, const int64_t* ld, hipStream_t st) -> int {
     const double* in[3] = {d[0], d[1], d[2]};
     double* out[4] = {d[3], d[4], dtau_da ? d[5] : nullptr, tau ? d[6] : nullptr};
-    return run(Bc, in, ld, out, ld + 3, st);
+    return run(Bc, in, ld, out, ld + 3, st, layout, -1);
   });
 }
 
@@ -1152,6 +1231,13 @@ int brbd_minverse(brbd_model* m, int64_t B, const double* q, int64_t ldq, double
   if (B == 0) return BRBD_OK;
   DevGuard dg(m->device);
   if (!dg.ok) return fail(BRBD_ERR_RUNTIME, "hipSetDevice failed");
+  if (memspace == BRBD_DEVICE && layout == BRBD_INSTANCE_MAJOR && B >= 4096 && via_bm_enabled()) {
+    const XpMat mats[2] = {{q, nullptr, ldq, F.nq}, {nullptr, Minv, ldminv, (int64_t)F.nv * F.nv}};
+    return via_batch_major(m, B, mats, 2, (hipStream_t)stream,
+                           [&](int64_t Bc, double** d, const int64_t* ld, hipStream_t st) -> int {
+                             return minverse_device(m, Bc, d[0], ld[0], d[1], ld[1], 0, BRBD_BATCH_MAJOR, st);
+                           });
+  }
   if (memspace == BRBD_DEVICE) return minverse_device(m, B, q, ldq, Minv, ldminv, 0, layout, (hipStream_t)stream);
   const HostMat mats[2] = {{q, nullptr, ldq, F.nq, true, false}, {nullptr, Minv, ldminv, nn, false, true}};
   return host_pipeline(m, B, layout, mats, 2, (hipStream_t)stream,
@@ -1210,6 +1296,21 @@ int brbd_aba_derivatives(brbd_model* m, int64_t B, const double* q, int64_t ldq,
     HIP_TRY(hipGetLastError());
     return BRBD_OK;
   };
+  if (memspace == BRBD_DEVICE && layout == BRBD_INSTANCE_MAJOR && B >= 4096 && via_bm_enabled()) {
+    // every stage is output-bound: the whole composition runs on batch-major copies
+    const XpMat mats[7] = {{q, nullptr, ldq, F.nq}, {v, nullptr, ldv, F.nv}, {tau, nullptr, ldtau, F.nv},
+                           {nullptr, ddq_dq, lddq, nn}, {nullptr, ddq_dv, lddv, nn}, {nullptr, ddq_dtau, lddtau, nn},
+                           {nullptr, ddq, ldddq, F.nv}};  // (ddq NULL: the copy is the temporary)
+    const int lay = layout;
+    layout = BRBD_BATCH_MAJOR;  // (run captures it by reference)
+    rc = via_batch_major(m, B, mats, 7, (hipStream_t)stream,
+                         [&](int64_t Bc, double** d, const int64_t* ld, hipStream_t st) -> int {
+                           return run(Bc, d[0], ld[0], d[1], ld[1], d[2], ld[2], d[3], ld[3], d[4], ld[4], d[5], ld[5],
+                                      d[6], ld[6], st);
+                         });
+    layout = lay;
+    return rc;
+  }
   if (memspace == BRBD_DEVICE) {
     hipStream_t st = (hipStream_t)stream;
     double* acc = ddq;
@@ -1314,8 +1415,9 @@ static int transpose_common(int device, int64_t dof, int64_t B, const double* sr
   if (ld_src < need_src || ld_dst < need_dst) return fail(BRBD_ERR_INVALID_ARGUMENT, "leading dimension too small");
   DevGuard dg(device);
   if (!dg.ok) return fail(BRBD_ERR_RUNTIME, "hipSetDevice failed");
-  const dim3 g((unsigned)((B + 31) / 32), (unsigned)((dof + 31) / 32)), b(256);
-  hipLaunchKernelGGL(transpose_kernel, g, b, 0, (hipStream_t)stream, src, ld_src, dst, ld_dst, dof, B, to_bm);
+  const dim3 g((unsigned)((B + 63) / 64)), b(256);
+  if (to_bm) hipLaunchKernelGGL(xpose64_kernel<1>, g, b, 0, (hipStream_t)stream, src, ld_src, dst, ld_dst, dof, B);
+  else hipLaunchKernelGGL(xpose64_kernel<0>, g, b, 0, (hipStream_t)stream, src, ld_src, dst, ld_dst, dof, B);
   HIP_TRY(hipGetLastError());
   return BRBD_OK;
 }

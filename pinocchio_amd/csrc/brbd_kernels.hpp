@@ -1186,33 +1186,52 @@ __global__ __launch_bounds__(WAVE) void jjac_kernel(const KArgs A) {
 
 // =================================================================================== layout helpers
 // dof x B instance-major (x[b*ld + d]) <-> batch-major (y[d*ld + b]) through a padded LDS tile.
-static __global__ __launch_bounds__(256) void transpose_kernel(const double* __restrict__ src, int64_t ld_src,
-                                                        double* __restrict__ dst, int64_t ld_dst,
-                                                        int64_t dof, int64_t B, int to_batch_major) {
-  __shared__ double tile[32][33];
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-  const int64_t b0 = (int64_t)blockIdx.x * 32, d0 = (int64_t)blockIdx.y * 32;
-  if (to_batch_major) {
-    // read rows of instances (contiguous in d), write rows of dofs (contiguous in b)
-    for (int i = ty; i < 32; i += 8) {
-      const int64_t b = b0 + i, d = d0 + tx;
-      if (b < B && d < dof) tile[i][tx] = src[b * ld_src + d];
+// 64 x 64 tiles, 512-byte runs on both sides: brbd_transpose_to_*, and the transposes the library
+// itself uses to run an INSTANCE_MAJOR call of an output-bound algorithm on the BATCH_MAJOR kernel
+// (brbd_capi.hip, via_batch_major).  TO_BM: src is instance-major (B x dof, ld_src), dst
+// batch-major (dof x B).  One workgroup owns 64 instances and walks over ALL their dofs: the
+// instance-major rows are rarely aligned to cache lines, and the partial lines where two 512-byte
+// runs meet are then written by the same CU within a few hundred cycles (one L2 merges them).
+template <int TO_BM>
+static __global__ __launch_bounds__(256) void xpose64_kernel(const double* __restrict__ src, int64_t ld_src,
+                                                             double* __restrict__ dst, int64_t ld_dst, int64_t dof,
+                                                             int64_t B) {
+  __shared__ double tile[64][65];
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;  // 4 waves: wave w moves rows w, w+4, ...
+  const int64_t b0 = (int64_t)blockIdx.x * 64;
+  // software pipeline: the loads of tile t+1 are in flight while tile t goes through LDS and out
+  double r[16];
+  auto load = [&](int64_t d0) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int i = w + 4 * k;
+      if (TO_BM) {
+        const int64_t b = b0 + i, d = d0 + l;
+        r[k] = (b < B && d < dof) ? src[b * ld_src + d] : 0.0;
+      } else {
+        const int64_t d = d0 + i, b = b0 + l;
+        r[k] = (b < B && d < dof) ? src[d * ld_src + b] : 0.0;
+      }
+    }
+  };
+  load(0);
+  for (int64_t d0 = 0; d0 < dof; d0 += 64) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) tile[w + 4 * k][l] = r[k];
+    __syncthreads();
+    if (d0 + 64 < dof) load(d0 + 64);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int i = w + 4 * k;
+      if (TO_BM) {
+        const int64_t d = d0 + i, b = b0 + l;
+        if (b < B && d < dof) dst[d * ld_dst + b] = tile[l][i];
+      } else {
+        const int64_t b = b0 + i, d = d0 + l;
+        if (b < B && d < dof) dst[b * ld_dst + d] = tile[l][i];
+      }
     }
     __syncthreads();
-    for (int i = ty; i < 32; i += 8) {
-      const int64_t d = d0 + i, b = b0 + tx;
-      if (b < B && d < dof) dst[d * ld_dst + b] = tile[tx][i];
-    }
-  } else {
-    for (int i = ty; i < 32; i += 8) {
-      const int64_t d = d0 + i, b = b0 + tx;
-      if (b < B && d < dof) tile[i][tx] = src[d * ld_src + b];
-    }
-    __syncthreads();
-    for (int i = ty; i < 32; i += 8) {
-      const int64_t b = b0 + i, d = d0 + tx;
-      if (b < B && d < dof) dst[b * ld_dst + d] = tile[tx][i];
-    }
   }
 }
 

@@ -22,6 +22,16 @@ def timed(dm, algo, fn, reps):
     n, ms = dm.kernel_time(algo)
     return ms / max(n, 1) * 1e-3 * (n / reps)   # seconds per call (chunked launches summed)
 
+def wall(fn, reps):
+    """seconds per call between two events on the current stream (everything the call enqueues:
+    kernels, transposes, copies)"""
+    for _ in range(2): fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(reps): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / reps
+
 which = sys.argv[1:] or ["fkjac", "aba", "rnea", "deriv", "fext", "jjac", "f4", "layouts"]
 if "fkjac" in which:
     m = S.arm7(); B = 1 << 20; pool = parallel.ModelPool(m, 1); dm = pool.device_model(0)
@@ -119,4 +129,40 @@ if "layouts" in which:   # the reference's own layout, device resident, against 
         r["rnea_instance_major_us"] = timed(dm, capi.ALGO_RNEA, lambda: parallel.rneaInParallel(1, pool, qi, vi, ai, taui), reps) * 1e6
         r["aba_instance_major_us"] = timed(dm, capi.ALGO_ABA, lambda: parallel.abaInParallel(1, pool, qi, vi, taui, ddqi), reps) * 1e6
         print(json.dumps(r))
+    pool.release()
+    # the output-bound kernels in the reference's layout (per-lane addressing, layout 0)
+    m = S.quadruped(); B = 1 << 18; pool = parallel.ModelPool(m, 1); dm = pool.device_model(0)
+    q, v, a = inputs(m, B)
+    qi, vi, ai = (x.t().contiguous().t() for x in (q, v, a))
+    nn = m.nv * m.nv
+    ob = [torch.empty((nn, B), dtype=torch.float64, device="cuda") for _ in range(3)]
+    oi = [torch.empty((B, nn), dtype=torch.float64, device="cuda").t() for _ in range(3)]
+    dm.outputs_prezeroed(False)
+    def call(qq, vv, aa, oo):
+        capi.check(capi.lib().brbd_rnea_derivatives(
+            dm.handle, B, qq.data_ptr(), qq.stride(1) if qq.stride(0) == 1 else qq.stride(0), vv.data_ptr(),
+            vv.stride(1) if vv.stride(0) == 1 else vv.stride(0), aa.data_ptr(), aa.stride(1) if aa.stride(0) == 1 else aa.stride(0),
+            oo[0].data_ptr(), max(oo[0].stride()), oo[1].data_ptr(), max(oo[1].stride()), oo[2].data_ptr(), max(oo[2].stride()),
+            None, 0, capi.INSTANCE_MAJOR if (qq.stride(0) == 1 and B > 1) else capi.BATCH_MAJOR, capi.DEVICE,
+            torch.cuda.current_stream().cuda_stream))
+    tb = wall(lambda: call(q, v, a, ob), 5)
+    ti = wall(lambda: call(qi, vi, ai, oi), 5)
+    print(json.dumps({"config": "quadruped RNEA derivatives B=262144 by layout (time per call, events on the stream)",
+                      "batch_major_us": tb * 1e6, "instance_major_us": ti * 1e6,
+                      "via_bm": os.environ.get("BRBD_DISABLE_VIA_BM", "0") != "1", "chunk": os.environ.get("BRBD_VIA_BM_CHUNK", "default")}))
+    tb = wall(lambda: parallel.computeMinverse(pool, q), 3)
+    ti = wall(lambda: parallel.computeMinverse(pool, qi), 3)
+    print(json.dumps({"config": "quadruped computeMinverse B=262144 by layout (time per call incl. output allocation)",
+                      "batch_major_us": tb * 1e6, "instance_major_us": ti * 1e6}))
+    tb = wall(lambda: parallel.computeABADerivatives(pool, q, v, a), 3)
+    ti = wall(lambda: parallel.computeABADerivatives(pool, qi, vi, ai), 3)
+    print(json.dumps({"config": "quadruped computeABADerivatives B=262144 by layout (time per call incl. output allocation)",
+                      "batch_major_us": tb * 1e6, "instance_major_us": ti * 1e6}))
+    pool.release()
+    m = S.arm7(); B = 1 << 20; pool = parallel.ModelPool(m, 1); dm = pool.device_model(0)
+    q, _, _ = inputs(m, B)
+    qi = q.t().contiguous().t()
+    tb = timed(dm, capi.ALGO_FK_JAC, lambda: parallel.computeJointJacobians(pool, q), 10)
+    ti = timed(dm, capi.ALGO_FK_JAC, lambda: parallel.computeJointJacobians(pool, qi), 10)
+    print(json.dumps({"config": "arm7 FK+J (J only) B=1048576 by layout", "batch_major_us": tb * 1e6, "instance_major_us": ti * 1e6}))
     pool.release()

@@ -11,9 +11,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <condition_variable>
 #include <map>
 #include <memory>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -75,6 +78,8 @@ struct StreamCtx {
   size_t tmp_doubles = 0;
   double* d_xp = nullptr;     // via_batch_major: batch-major copies of one column chunk
   size_t xp_doubles = 0;
+  double* h_stage = nullptr;  // pageable host matrices: two chunk slots of pinned bounce buffers
+  size_t hstage_doubles = 0;
   hipStream_t pipe[2] = {nullptr, nullptr};  // internal streams of the host-memspace pipeline
   hipEvent_t ev_in = nullptr, ev_done[2] = {nullptr, nullptr};
 };
@@ -194,6 +199,7 @@ void free_ctx(StreamCtx& c) {
   if (c.d_stage) (void)hipFree(c.d_stage);
   if (c.d_tmp) (void)hipFree(c.d_tmp);
   if (c.d_xp) (void)hipFree(c.d_xp);
+  if (c.h_stage) (void)hipHostFree(c.h_stage);
   for (int k = 0; k < 2; ++k) {
     if (c.ev_done[k]) (void)hipEventDestroy(c.ev_done[k]);
     if (c.pipe[k]) (void)hipStreamDestroy(c.pipe[k]);
@@ -767,6 +773,132 @@ struct HostMat {
 
 size_t padded(size_t doubles) { return (doubles + 31) & ~size_t(31); }
 
+// ---- pageable host matrices: packed by worker threads into pinned bounce buffers ------------------
+// hipMemcpyAsync from pageable memory is staged by the runtime on the calling thread (measured:
+// 2.0e7 evals/s for the humanoid step against 4.5e7 from pinned memory).  The reference's callers
+// hold plain Eigen matrices, so the library does that staging itself, in parallel: worker threads
+// copy the chunk's columns into a pinned image (and the results back out of one) while the DMA
+// engines and the kernels work on the neighbouring chunk.
+struct CopyTask {
+  char* dst;
+  const char* src;
+  size_t dpitch, spitch, width, rows;
+};
+
+class CopyPool {  // one per process; parallel_run calls are serialised
+ public:
+  static CopyPool& get() {
+    static CopyPool* p = new CopyPool();  // (never destroyed: workers may outlive static destructors)
+    return *p;
+  }
+  int threads() const { return nthreads_; }
+  void run(const std::vector<CopyTask>& tasks) {
+    if (tasks.empty()) return;
+    if (nthreads_ <= 1 || tasks.size() == 1) {
+      for (const CopyTask& t : tasks) do_task(t);
+      return;
+    }
+    std::lock_guard<std::mutex> serial(run_mu_);
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      tasks_ = &tasks;
+      next_.store(0);
+      pending_ = (int)workers_.size();
+      ++generation_;
+    }
+    cv_.notify_all();
+    work();  // the calling thread takes tasks too
+    std::unique_lock<std::mutex> g(mu_);
+    done_cv_.wait(g, [&] { return pending_ == 0; });
+    tasks_ = nullptr;
+  }
+
+ private:
+  CopyPool() {
+    const char* e = getenv("BRBD_HOST_THREADS");
+    int n = e ? atoi(e) : 6;  // (measured: 4 saturate the copies of one GPU)
+    const int hw = (int)std::thread::hardware_concurrency();
+    if (hw > 0 && n > hw) n = hw;
+    if (n < 0) n = 0;
+    nthreads_ = n;
+    for (int k = 1; k < n; ++k) {
+      workers_.emplace_back([this] { loop(); });
+      workers_.back().detach();
+    }
+  }
+  static void do_task(const CopyTask& t) {
+    for (size_t r = 0; r < t.rows; ++r) memcpy(t.dst + r * t.dpitch, t.src + r * t.spitch, t.width);
+  }
+  void work() {
+    const std::vector<CopyTask>& T = *tasks_;
+    for (size_t k = next_.fetch_add(1); k < T.size(); k = next_.fetch_add(1)) do_task(T[k]);
+  }
+  void loop() {
+    unsigned long long seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> g(mu_);
+        cv_.wait(g, [&] { return generation_ != seen; });
+        seen = generation_;
+      }
+      work();
+      std::lock_guard<std::mutex> g(mu_);
+      if (--pending_ == 0) done_cv_.notify_one();
+    }
+  }
+  int nthreads_ = 0;
+  std::vector<std::thread> workers_;
+  std::mutex mu_, run_mu_;
+  std::condition_variable cv_, done_cv_;
+  const std::vector<CopyTask>* tasks_ = nullptr;
+  std::atomic<size_t> next_{0};
+  int pending_ = 0;
+  unsigned long long generation_ = 0;
+};
+
+// split a pitched 2-D copy into tasks of about 128 KiB
+void add_copy_tasks(std::vector<CopyTask>& out, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width,
+                    size_t rows) {
+  const size_t grain = 128 * 1024;
+  if (width == 0 || rows == 0) return;
+  if (dpitch == width && spitch == width) {  // one contiguous block
+    width *= rows;
+    rows = 1;
+  }
+  if (width >= grain) {
+    for (size_t r = 0; r < rows; ++r)
+      for (size_t c = 0; c < width; c += grain)
+        out.push_back({(char*)dst + r * dpitch + c, (const char*)src + r * spitch + c, 0, 0,
+                       width - c < grain ? width - c : grain, 1});
+  } else {
+    const size_t per = grain / width;
+    for (size_t r = 0; r < rows; r += per)
+      out.push_back({(char*)dst + r * dpitch, (const char*)src + r * spitch, dpitch, spitch, width,
+                     rows - r < per ? rows - r : per});
+  }
+}
+
+bool is_device_visible_host(const void* p) {  // pinned / registered host memory?
+  if (!p) return true;
+  hipPointerAttribute_t a;
+  memset(&a, 0, sizeof a);
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+    (void)hipGetLastError();  // (plain malloc memory: invalid value on older runtimes)
+    return false;
+  }
+  return a.type == hipMemoryTypeHost;
+}
+
+int ensure_host_buf(double** buf, size_t* have, size_t doubles) {
+  if (doubles <= *have) return BRBD_OK;
+  if (*buf) HIP_TRY(hipHostFree(*buf));
+  *buf = nullptr;
+  *have = 0;
+  HIP_TRY(hipHostMalloc((void**)buf, doubles * sizeof(double), hipHostMallocDefault));
+  *have = doubles;
+  return BRBD_OK;
+}
+
 int64_t host_chunk(int64_t B) {
   static const int64_t forced = getenv("BRBD_HOST_CHUNK") ? atoll(getenv("BRBD_HOST_CHUNK")) : 0;
   if (forced > 0) return ((forced + WAVE - 1) / WAVE) * WAVE;
@@ -781,7 +913,14 @@ template <typename Launch>
 int host_pipeline(brbd_model* m, int64_t B, int layout, const HostMat* mats, int nm, hipStream_t user,
                   Launch launch) {
   StreamCtx* ctx = get_ctx(m, user);
-  const int64_t C = host_chunk(B) < B ? host_chunk(B) : ((B + WAVE - 1) / WAVE) * WAVE;
+  int64_t C = host_chunk(B) < B ? host_chunk(B) : ((B + WAVE - 1) / WAVE) * WAVE;
+  {  // at most 128 MiB per staging slot (the derivative matrices: 3 nv^2 doubles per instance)
+    int64_t tot = 0;
+    for (int i = 0; i < nm; ++i) tot += mats[i].dof;
+    int64_t cap = ((int64_t)(128u << 20) / 8 / (tot > 0 ? tot : 1) / WAVE) * WAVE;
+    if (cap < 256) cap = 256;
+    if (C > cap) C = cap;
+  }
   const int64_t nchunks = (B + C - 1) / C;
   size_t off[16], slot = 0;
   for (int i = 0; i < nm; ++i) {
@@ -836,6 +975,87 @@ int host_pipeline(brbd_model* m, int64_t B, int layout, const HostMat* mats, int
       if (mats[i].down) HIP_TRY(copy(i, c0, Bc, base + off[i], false, ctx->pipe[sl]));
     return BRBD_OK;
   };
+  // pageable host memory, enough of it: the library's own pinned bounce buffers (see CopyPool)
+  bool pageable = false;
+  size_t total_bytes = 0;
+  for (int i = 0; i < nm; ++i) {
+    if (mats[i].up && !is_device_visible_host(mats[i].src)) pageable = true;
+    if (mats[i].down && !is_device_visible_host(mats[i].dst)) pageable = true;
+    total_bytes += (size_t)mats[i].dof * (size_t)B * 8 * ((mats[i].up ? 1 : 0) + (mats[i].down ? 1 : 0));
+  }
+  if (pageable && CopyPool::get().threads() >= 1 && total_bytes >= (size_t)(4u << 20)) {
+    if ((rc = ensure_host_buf(&ctx->h_stage, &ctx->hstage_doubles, (nchunks > 1 ? 2 : 1) * slot))) return rc;
+    std::vector<CopyTask> tasks;
+    auto geometry = [&](int i, int64_t Bc, size_t& hpitch, size_t& ipitch, size_t& width, size_t& height) {
+      hpitch = (size_t)mats[i].ld * 8;                 // the caller's matrix
+      ipitch = (size_t)(bm ? C : mats[i].dof) * 8;     // its tight image (pinned and device alike)
+      width = (size_t)(bm ? Bc : mats[i].dof) * 8;
+      height = (size_t)(bm ? mats[i].dof : Bc);
+    };
+    auto pack = [&](int64_t k) {  // caller's columns of chunk k -> pinned image
+      const int sl = (int)(k & 1);
+      const int64_t c0 = k * C, Bc = B - c0 < C ? B - c0 : C;
+      tasks.clear();
+      for (int i = 0; i < nm; ++i) {
+        if (!mats[i].up || !mats[i].dof) continue;
+        size_t hp, ip, w, h;
+        geometry(i, Bc, hp, ip, w, h);
+        add_copy_tasks(tasks, ctx->h_stage + (size_t)sl * slot + off[i], ip, mats[i].src + (bm ? c0 : c0 * mats[i].ld), hp, w, h);
+      }
+      CopyPool::get().run(tasks);
+    };
+    auto submit = [&](int64_t k) -> int {  // pinned image -> device, kernels, results -> pinned image
+      const int sl = (int)(k & 1);
+      const int64_t c0 = k * C, Bc = B - c0 < C ? B - c0 : C;
+      double* dbase = ctx->d_stage + (size_t)sl * slot;
+      double* hbase = ctx->h_stage + (size_t)sl * slot;
+      double* dev[16];
+      int64_t ldd[16];
+      for (int i = 0; i < nm; ++i) {
+        dev[i] = dbase + off[i];
+        ldd[i] = bm ? C : mats[i].dof;
+        if (!mats[i].dof) continue;
+        size_t hp, ip, w, h;
+        geometry(i, Bc, hp, ip, w, h);
+        if (mats[i].up) HIP_TRY(hipMemcpyAsync(dev[i], hbase + off[i], ip * h, hipMemcpyHostToDevice, ctx->pipe[sl]));
+      }
+      int r = launch(Bc, dev, ldd, ctx->pipe[sl]);
+      if (r) return r;
+      for (int i = 0; i < nm; ++i) {
+        if (!mats[i].down || !mats[i].dof) continue;
+        size_t hp, ip, w, h;
+        geometry(i, Bc, hp, ip, w, h);
+        HIP_TRY(hipMemcpyAsync(hbase + off[i], dev[i], ip * h, hipMemcpyDeviceToHost, ctx->pipe[sl]));
+      }
+      HIP_TRY(hipEventRecord(ctx->ev_done[sl], ctx->pipe[sl]));
+      return BRBD_OK;
+    };
+    auto unpack = [&](int64_t k) -> int {  // pinned image -> caller's columns, once the chunk is done
+      const int sl = (int)(k & 1);
+      const int64_t c0 = k * C, Bc = B - c0 < C ? B - c0 : C;
+      HIP_TRY(hipEventSynchronize(ctx->ev_done[sl]));
+      tasks.clear();
+      for (int i = 0; i < nm; ++i) {
+        if (!mats[i].down || !mats[i].dof) continue;
+        size_t hp, ip, w, h;
+        geometry(i, Bc, hp, ip, w, h);
+        add_copy_tasks(tasks, mats[i].dst + (bm ? c0 : c0 * mats[i].ld), hp, ctx->h_stage + (size_t)sl * slot + off[i], ip, w, h);
+      }
+      CopyPool::get().run(tasks);
+      return BRBD_OK;
+    };
+    pack(0);
+    if ((rc = submit(0))) return rc;
+    for (int64_t k = 0; k < nchunks; ++k) {
+      if (k + 1 < nchunks) {  // (slot (k+1)&1 was unpacked in the previous iteration)
+        pack(k + 1);
+        if ((rc = submit(k + 1))) return rc;
+      }
+      if ((rc = unpack(k))) return rc;
+    }
+    for (int k = 0; k < 2; ++k) HIP_TRY(hipStreamSynchronize(ctx->pipe[k]));
+    return BRBD_OK;
+  }
   // software pipeline: the upload of chunk k + 1 is queued before the download of chunk k, so that a
   // host thread blocked in a pageable copy still leaves the GPU with work
   if ((rc = stage_in(0))) return rc;

@@ -43,12 +43,15 @@ def _canaries_intact(buf, view, guard, ld, inner):
 
 @pytest.mark.parametrize("layout", [capi.INSTANCE_MAJOR, capi.BATCH_MAJOR], ids=["instance_major", "batch_major"])
 @pytest.mark.parametrize("name", ["simple_humanoid", "random_tree"])
-def test_host_memspace_padded_exact_buffers(layout, name):
+@pytest.mark.parametrize("B", [300, 9000], ids=["direct_copies", "bounce_buffers"])
+def test_host_memspace_padded_exact_buffers(layout, name, B):
+    """B = 300: the runtime's own pageable copies (hipMemcpy2DAsync); B = 9000: above the 4 MiB
+    threshold, the library's worker threads pack / unpack pinned bounce buffers."""
     L = capi.lib()
     model = S.build(name) if name != "random_tree" else S.random_tree(104, 10)
     dm = capi.DeviceModel(model, 0)
     O = oracle.Oracle(model)
-    B, pad = 300, 5
+    pad = 5
     q, v, a = inputs(model, B, 8)
     tau_ref = O.rnea(q, v, a)
     nan = np.full((model.nv, B), np.nan)

@@ -10,6 +10,8 @@ D=/tmp/cgv_$TAG; rm -rf $D; mkdir -p $D/gen
 env "$@" python -m pinocchio_amd.codegen.build --out $D/gen --models $MODEL --variants p 2>/dev/null
 FLAGS="$EXTRA -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-unused-variable -Wno-unused-but-set-variable -I pinocchio_amd/csrc"
 sed -i 's#"../brbd_spec.hpp"#"brbd_spec.hpp"#' $D/gen/spec_*.hip
+# KATTR: extra kernel attribute, e.g. KATTR='__attribute__((amdgpu_waves_per_eu(2,2)))'
+if [ -n "$KATTR" ]; then sed -i "s/__launch_bounds__(WAVE)/__launch_bounds__(WAVE) $KATTR/" $D/gen/*.kern.inc; fi
 sed -e 's#"gen/registry.inc"#"'$D'/gen/registry.inc"#' -e 's#"../../include/brbd.h"#"brbd.h"#' pinocchio_amd/csrc/brbd_capi.hip > $D/gen/spec_capi.hip
 ls $D/gen/spec_*.hip | xargs -P 8 -I{} sh -c "/opt/rocm/bin/hipcc $FLAGS -I include -I $D/gen -c -o {}.o {} -Rpass-analysis=kernel-resource-usage 2> {}.usage || { grep error {}.usage; exit 255; }"
 cat $D/gen/*.usage | grep -E "Function Name|VGPRs:|AGPRs|Scratch|SGPRs Spill|VGPRs Spill" | grep -A5 "k_rneaIL\|k_abaIL\|k_derivIL" | sed 's/.*remark: *//;s/\[-Rpass.*//' | tr "\n" " " | sed "s/Function Name: _ZN4brbd[0-9]*spec_${MODEL}_p/\n/g"; echo

@@ -183,7 +183,8 @@ int brbd_aba_noalloc(brbd_model* m, int64_t B, const double* q, int64_t ldq, con
 
 /* Page-lock / release a host range (hipHostRegister / hipHostUnregister) so that BRBD_HOST calls on
  * matrices inside it copy by DMA and overlap upload, kernels and download; the caller must
- * unregister before freeing the memory.  Optional: pageable memory works, only slower.  No
+ * unregister before freeing the memory.  Optional: pageable memory works (the library packs it
+ * into its own pinned bounce buffers with a few worker threads), about 20 % slower.  No
  * reference counterpart (the reference never leaves host memory). */
 int brbd_host_register(void* ptr, size_t bytes);
 int brbd_host_unregister(void* ptr);
@@ -215,7 +216,11 @@ int brbd_joint_jacobian(brbd_model* m, int64_t B, const double* q, int64_t ldq, 
  * the engine writes every element (structural zeros included); dtau_da holds
  * the UPPER triangle of M like the reference (plus the full nvj x nvj diagonal
  * block of multi-dof joints, as rnea-derivatives.hxx:420-421 writes it).
- * dtau_da and tau may be NULL. */
+ * dtau_da and tau may be NULL.
+ * BRBD_DEVICE + BRBD_INSTANCE_MAJOR with B >= 4096 (also brbd_minverse,
+ * brbd_aba_derivatives): the call runs on batch-major copies of column chunks
+ * that the handle keeps per stream (up to 1 GiB) and transposes the results
+ * into the caller's matrices; same values as the BRBD_BATCH_MAJOR call. */
 int brbd_rnea_derivatives(brbd_model* m, int64_t B, const double* q, int64_t ldq, const double* v,
                           int64_t ldv, const double* a, int64_t lda, double* dtau_dq, int64_t lddq,
                           double* dtau_dv, int64_t lddv, double* dtau_da, int64_t ldda, double* tau,

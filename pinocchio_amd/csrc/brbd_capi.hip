@@ -99,7 +99,7 @@ struct brbd_model {
   int max_waves[4] = {0, 0, 0, 0};
   int max_waves_spec[4] = {0, 0, 0, 0};
   int max_waves_jjac = 0;
-  int max_waves_f4[3] = {0, 0, 0};  // minverse, integrate, aba-derivative products
+  int max_waves_f4[4] = {0, 0, 0, 0};  // minverse, integrate, aba-derivative products (nv <= 24, nv <= 48)
   std::map<int, std::pair<Op*, int>> chains;  // brbd_joint_jacobian: support chain of a joint (device)
   // model-compiled kernels (brbd_spec.hpp), when the model's signature is registered
   const SpecEntry* spec = nullptr;
@@ -1505,13 +1505,15 @@ int brbd_aba_derivatives(brbd_model* m, int64_t B, const double* q, int64_t ldq,
     F4Args A{};
     fill_f4(m, A, Bc);
     A.out = o1; A.ldout = lo1; A.out2 = o2; A.ldout2 = lo2; A.minv = o3; A.ldminv = lo3;
-    const int grid = f4_grid(m, m->max_waves_f4[2], aba_deriv_product_kernel<1, 48>, A.ntiles);
+    // (4 columns of both factors in registers for nv <= 24, 2 for nv <= 48: about 200 doubles)
+    const int grid = F.nv <= 24 ? f4_grid(m, m->max_waves_f4[2], aba_deriv_product_kernel<1, 24, 4>, A.ntiles)
+                                : f4_grid(m, m->max_waves_f4[3], aba_deriv_product_kernel<1, 48, 2>, A.ntiles);
     if (layout == BRBD_BATCH_MAJOR) {
-      if (F.nv <= 24) hipLaunchKernelGGL((aba_deriv_product_kernel<1, 24>), dim3(grid), dim3(WAVE), 0, st, A);
-      else hipLaunchKernelGGL((aba_deriv_product_kernel<1, 48>), dim3(grid), dim3(WAVE), 0, st, A);
+      if (F.nv <= 24) hipLaunchKernelGGL((aba_deriv_product_kernel<1, 24, 4>), dim3(grid), dim3(WAVE), 0, st, A);
+      else hipLaunchKernelGGL((aba_deriv_product_kernel<1, 48, 2>), dim3(grid), dim3(WAVE), 0, st, A);
     } else {
-      if (F.nv <= 24) hipLaunchKernelGGL((aba_deriv_product_kernel<0, 24>), dim3(grid), dim3(WAVE), 0, st, A);
-      else hipLaunchKernelGGL((aba_deriv_product_kernel<0, 48>), dim3(grid), dim3(WAVE), 0, st, A);
+      if (F.nv <= 24) hipLaunchKernelGGL((aba_deriv_product_kernel<0, 24, 4>), dim3(grid), dim3(WAVE), 0, st, A);
+      else hipLaunchKernelGGL((aba_deriv_product_kernel<0, 48, 2>), dim3(grid), dim3(WAVE), 0, st, A);
     }
     HIP_TRY(hipGetLastError());
     return BRBD_OK;

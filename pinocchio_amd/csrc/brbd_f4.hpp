@@ -343,8 +343,10 @@ __global__ __launch_bounds__(WAVE) void minverse_kernel(const F4Args A) {
 
 // ---------------------------------------------------------- closing products of computeABADerivatives
 // In place: out (holding dtau_dq) <- -Minv * out, out2 (dtau_dv) <- -Minv * out2; Minv full symmetric.
-// Column c of a product depends on column c of the factor only: it is held in registers.
-template <int LAYOUT, int NVMAX>
+// Column c of a product depends on column c of the factor only: CB columns of both factors are held
+// in registers (2 * CB * NVMAX doubles) while Minv streams past once per column block -- Minv is the
+// operand that is re-read (nv / CB times; from L2 / HBM: 64 instances' matrices do not fit a cache).
+template <int LAYOUT, int NVMAX, int CB>
 __global__ __launch_bounds__(WAVE) void aba_deriv_product_kernel(const F4Args A) {
   const int lane = threadIdx.x;
   const int nv = A.nv;
@@ -352,23 +354,36 @@ __global__ __launch_bounds__(WAVE) void aba_deriv_product_kernel(const F4Args A)
     const Mat<LAYOUT> Mi(const_cast<double*>(A.minv), A.ldminv, tile, A.B, lane);
     const Mat<LAYOUT> D1(A.out, A.ldout, tile, A.B, lane);
     const Mat<LAYOUT> D2(A.out2, A.ldout2, tile, A.B, lane);
-    for (int c = 0; c < nv; ++c) {
-      double c1[NVMAX], c2[NVMAX];
+    for (int c0 = 0; c0 < nv; c0 += CB) {
+      double c1[CB][NVMAX], c2[CB][NVMAX];
 #pragma unroll
-      for (int k = 0; k < NVMAX; ++k) {
-        c1[k] = k < nv ? D1.get(c * nv + k) : 0.0;
-        c2[k] = k < nv ? D2.get(c * nv + k) : 0.0;
-      }
-      for (int r = 0; r < nv; ++r) {
-        double s1 = 0.0, s2 = 0.0;
+      for (int j = 0; j < CB; ++j) {
+        const bool col = c0 + j < nv;
 #pragma unroll
         for (int k = 0; k < NVMAX; ++k) {
-          const double mrk = k < nv ? Mi.get(k * nv + r) : 0.0;  // Minv(r, k)
-          s1 += mrk * c1[k];
-          s2 += mrk * c2[k];
+          c1[j][k] = (col && k < nv) ? D1.get((c0 + j) * nv + k) : 0.0;
+          c2[j][k] = (col && k < nv) ? D2.get((c0 + j) * nv + k) : 0.0;
         }
-        D1.put(c * nv + r, -s1);
-        D2.put(c * nv + r, -s2);
+      }
+      for (int r = 0; r < nv; ++r) {
+        double s1[CB], s2[CB];
+#pragma unroll
+        for (int j = 0; j < CB; ++j) s1[j] = s2[j] = 0.0;
+#pragma unroll
+        for (int k = 0; k < NVMAX; ++k) {
+          const double mrk = k < nv ? Mi.get(k * nv + r) : 0.0;  // Minv(r, k) = Minv(k, r)
+#pragma unroll
+          for (int j = 0; j < CB; ++j) {
+            s1[j] += mrk * c1[j][k];
+            s2[j] += mrk * c2[j][k];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < CB; ++j)
+          if (c0 + j < nv) {
+            D1.put((c0 + j) * nv + r, -s1[j]);
+            D2.put((c0 + j) * nv + r, -s2[j]);
+          }
       }
     }
   }

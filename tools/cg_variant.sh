@@ -11,6 +11,8 @@ env "$@" python -m pinocchio_amd.codegen.build --out $D/gen --models $MODEL --va
 FLAGS="$EXTRA -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-unused-variable -Wno-unused-but-set-variable -I pinocchio_amd/csrc"
 sed -i 's#"../brbd_spec.hpp"#"brbd_spec.hpp"#' $D/gen/spec_*.hip
 # KATTR: extra kernel attribute, e.g. KATTR='__attribute__((amdgpu_waves_per_eu(2,2)))'
+# NOBAR="rnea aba": drop the scheduling barriers between the visits of these algorithms' bodies
+for alg in $NOBAR; do sed -i 's/^VISIT_END();$//' $D/gen/*_$alg.inc; done
 if [ -n "$KATTR" ]; then sed -i "s/__launch_bounds__(WAVE)/__launch_bounds__(WAVE) $KATTR/" $D/gen/*.kern.inc; fi
 sed -e 's#"gen/registry.inc"#"'$D'/gen/registry.inc"#' -e 's#"../../include/brbd.h"#"brbd.h"#' pinocchio_amd/csrc/brbd_capi.hip > $D/gen/spec_capi.hip
 ls $D/gen/spec_*.hip | xargs -P 8 -I{} sh -c "/opt/rocm/bin/hipcc $FLAGS -I include -I $D/gen -c -o {}.o {} -Rpass-analysis=kernel-resource-usage 2> {}.usage || { grep error {}.usage; exit 255; }"

@@ -1272,6 +1272,51 @@ int brbd_joint_jacobian(brbd_model* m, int64_t B, const double* q, int64_t ldq, 
   });
 }
 
+// computeRNEADerivatives on device matrices: in[0..2] = q, v, a; out[0..3] = dtau_dq, dtau_dv, dtau_da, tau
+// (the last two may be NULL).  prezeroed: -1 = the handle's output contract, 0 / 1 = this call's.
+extern "C++" {
+namespace {
+int deriv_device(brbd_model* m, int64_t Bc, const double* const* in, const int64_t* ldi, double* const* out,
+                 const int64_t* ldo, hipStream_t st, int layout, int pz) {
+  const FlatModel& F = m->flat;
+  if (m->spec && m->use_spec) {  // model-compiled kernel (codegen/deriv.py), when registered
+    KArgs A{};
+    fill_common(m, A, Bc);
+    A.q = in[0]; A.ldq = ldi[0]; A.v = in[1]; A.ldv = ldi[1]; A.a = in[2]; A.lda = ldi[2];
+    A.out = out[0]; A.ldout = ldo[0]; A.out2 = out[1]; A.ldout2 = ldo[1]; A.out3 = out[2]; A.ldout3 = ldo[2];
+    A.out4 = out[3]; A.ldout4 = ldo[3];
+    const int r = launch_algo(m, BRBD_ALGO_RNEA_DERIV, A, layout, st, nullptr, pz);
+    if (r <= 0) return r;  // 1 = no compiled kernel applies
+  }
+  DerivArgs D{};
+  D.tab = m->d_tab;
+  D.nvsub = m->d_nvsub;
+  D.njoints = F.njoints; D.nq = F.nq; D.nv = F.nv;
+  D.B = Bc;
+  D.ntiles = (Bc + WAVE - 1) / WAVE;
+  D.gx = F.gravity[0]; D.gy = F.gravity[1]; D.gz = F.gravity[2];
+  D.q = in[0]; D.ldq = ldi[0]; D.v = in[1]; D.ldv = ldi[1]; D.a = in[2]; D.lda = ldi[2];
+  D.dq = out[0]; D.lddq = ldo[0]; D.dv = out[1]; D.lddv = ldo[1]; D.da = out[2]; D.ldda = ldo[2];
+  D.tau = out[3]; D.ldtau = ldo[3];
+  if (m->max_waves[BRBD_ALGO_RNEA_DERIV] == 0)
+    m->max_waves[BRBD_ALGO_RNEA_DERIV] = resident_waves(m, rnea_deriv_kernel<1>, WAVE);
+  const int64_t grid = D.ntiles < m->max_waves[3] ? D.ntiles : m->max_waves[3];
+  D.ws_stride = (int64_t)deriv_ws_per_lane(F) * WAVE;
+  StreamCtx* ctx = get_ctx(m, st);
+  int r = ensure_buf(&ctx->d_ws, &ctx->ws_doubles, (size_t)grid * D.ws_stride, st);
+  if (r) return r;
+  D.ws = ctx->d_ws;
+  Timer tm{m, BRBD_ALGO_RNEA_DERIV, st};
+  if ((r = tm.begin())) return r;
+  const dim3 g((unsigned)grid), b(WAVE);
+  if (layout == BRBD_BATCH_MAJOR) hipLaunchKernelGGL(rnea_deriv_kernel<1>, g, b, 0, st, D);
+  else hipLaunchKernelGGL(rnea_deriv_kernel<0>, g, b, 0, st, D);
+  HIP_TRY(hipGetLastError());
+  return tm.end();
+}
+}  // namespace
+}  // extern "C++"
+
 int brbd_rnea_derivatives(brbd_model* m, int64_t B, const double* q, int64_t ldq, const double* v,
                           int64_t ldv, const double* a, int64_t lda, double* dtau_dq, int64_t lddq,
                           double* dtau_dv, int64_t lddv, double* dtau_da, int64_t ldda, double* tau,
@@ -1295,44 +1340,8 @@ int brbd_rnea_derivatives(brbd_model* m, int64_t B, const double* q, int64_t ldq
   DevGuard dg(m->device);
   if (!dg.ok) return fail(BRBD_ERR_RUNTIME, "hipSetDevice failed");
   hipStream_t s = (hipStream_t)stream;
-  // in[0..2] = q, v, a; out[0..3] = dtau_dq, dtau_dv, dtau_da, tau (the last two may be NULL)
   auto run = [&](int64_t Bc, const double* const* in, const int64_t* ldi, double* const* out, const int64_t* ldo,
-                 hipStream_t st, int layout, int pz) -> int {
-    if (m->spec && m->use_spec) {  // model-compiled kernel (codegen/deriv.py), when registered
-      KArgs A{};
-      fill_common(m, A, Bc);
-      A.q = in[0]; A.ldq = ldi[0]; A.v = in[1]; A.ldv = ldi[1]; A.a = in[2]; A.lda = ldi[2];
-      A.out = out[0]; A.ldout = ldo[0]; A.out2 = out[1]; A.ldout2 = ldo[1]; A.out3 = out[2]; A.ldout3 = ldo[2];
-      A.out4 = out[3]; A.ldout4 = ldo[3];
-      const int r = launch_algo(m, BRBD_ALGO_RNEA_DERIV, A, layout, st, nullptr, pz);
-      if (r <= 0) return r;  // 1 = no compiled kernel applies
-    }
-    DerivArgs D{};
-    D.tab = m->d_tab;
-    D.nvsub = m->d_nvsub;
-    D.njoints = F.njoints; D.nq = F.nq; D.nv = F.nv;
-    D.B = Bc;
-    D.ntiles = (Bc + WAVE - 1) / WAVE;
-    D.gx = F.gravity[0]; D.gy = F.gravity[1]; D.gz = F.gravity[2];
-    D.q = in[0]; D.ldq = ldi[0]; D.v = in[1]; D.ldv = ldi[1]; D.a = in[2]; D.lda = ldi[2];
-    D.dq = out[0]; D.lddq = ldo[0]; D.dv = out[1]; D.lddv = ldo[1]; D.da = out[2]; D.ldda = ldo[2];
-    D.tau = out[3]; D.ldtau = ldo[3];
-    if (m->max_waves[BRBD_ALGO_RNEA_DERIV] == 0)
-      m->max_waves[BRBD_ALGO_RNEA_DERIV] = resident_waves(m, rnea_deriv_kernel<1>, WAVE);
-    const int64_t grid = D.ntiles < m->max_waves[3] ? D.ntiles : m->max_waves[3];
-    D.ws_stride = (int64_t)deriv_ws_per_lane(F) * WAVE;
-    StreamCtx* ctx = get_ctx(m, st);
-    int r = ensure_buf(&ctx->d_ws, &ctx->ws_doubles, (size_t)grid * D.ws_stride, st);
-    if (r) return r;
-    D.ws = ctx->d_ws;
-    Timer tm{m, BRBD_ALGO_RNEA_DERIV, st};
-    if ((r = tm.begin())) return r;
-    const dim3 g((unsigned)grid), b(WAVE);
-    if (layout == BRBD_BATCH_MAJOR) hipLaunchKernelGGL(rnea_deriv_kernel<1>, g, b, 0, st, D);
-    else hipLaunchKernelGGL(rnea_deriv_kernel<0>, g, b, 0, st, D);
-    HIP_TRY(hipGetLastError());
-    return tm.end();
-  };
+                 hipStream_t st, int lay, int pz) -> int { return deriv_device(m, Bc, in, ldi, out, ldo, st, lay, pz); };
   if (memspace == BRBD_DEVICE) {
     const double* in[3] = {q, v, a};
     const int64_t ldi[3] = {ldq, ldv, lda};
@@ -1492,15 +1501,16 @@ int brbd_aba_derivatives(brbd_model* m, int64_t B, const double* q, int64_t ldq,
   // the closing products (:452-453).  All on one stream, in order.
   auto run = [&](int64_t Bc, const double* dq, int64_t l0, const double* dv, int64_t l1, const double* dt, int64_t l2,
                  double* o1, int64_t lo1, double* o2, int64_t lo2, double* o3, int64_t lo3, double* acc, int64_t la,
-                 hipStream_t st) -> int {
+                 hipStream_t st, int layout) -> int {
     int r = brbd_aba(m, Bc, dq, l0, dv, l1, dt, l2, acc, la, layout, BRBD_DEVICE, st);
     if (r) return r;
-    const bool pz = m->prezeroed;
-    m->prezeroed = false;  // the products read every element of the two matrices
-    r = brbd_rnea_derivatives(m, Bc, dq, l0, dv, l1, acc, la, o1, lo1, o2, lo2, nullptr, 0, nullptr, 0, layout,
-                              BRBD_DEVICE, st);
-    m->prezeroed = pz;
-    if (r) return r;
+    {  // every element written (prezeroed = 0): the products read both matrices in full
+      const double* in[3] = {dq, dv, acc};
+      const int64_t ldi[3] = {l0, l1, la};
+      double* out[4] = {o1, o2, nullptr, nullptr};
+      const int64_t ldo[4] = {lo1, lo2, 0, 0};
+      if ((r = deriv_device(m, Bc, in, ldi, out, ldo, st, layout, 0))) return r;
+    }
     if ((r = minverse_device(m, Bc, dq, l0, o3, lo3, 1, layout, st))) return r;
     F4Args A{};
     fill_f4(m, A, Bc);
@@ -1523,15 +1533,11 @@ int brbd_aba_derivatives(brbd_model* m, int64_t B, const double* q, int64_t ldq,
     const XpMat mats[7] = {{q, nullptr, ldq, F.nq}, {v, nullptr, ldv, F.nv}, {tau, nullptr, ldtau, F.nv},
                            {nullptr, ddq_dq, lddq, nn}, {nullptr, ddq_dv, lddv, nn}, {nullptr, ddq_dtau, lddtau, nn},
                            {nullptr, ddq, ldddq, F.nv}};  // (ddq NULL: the copy is the temporary)
-    const int lay = layout;
-    layout = BRBD_BATCH_MAJOR;  // (run captures it by reference)
-    rc = via_batch_major(m, B, mats, 7, (hipStream_t)stream,
-                         [&](int64_t Bc, double** d, const int64_t* ld, hipStream_t st) -> int {
-                           return run(Bc, d[0], ld[0], d[1], ld[1], d[2], ld[2], d[3], ld[3], d[4], ld[4], d[5], ld[5],
-                                      d[6], ld[6], st);
-                         });
-    layout = lay;
-    return rc;
+    return via_batch_major(m, B, mats, 7, (hipStream_t)stream,
+                           [&](int64_t Bc, double** d, const int64_t* ld, hipStream_t st) -> int {
+                             return run(Bc, d[0], ld[0], d[1], ld[1], d[2], ld[2], d[3], ld[3], d[4], ld[4], d[5],
+                                        ld[5], d[6], ld[6], st, BRBD_BATCH_MAJOR);
+                           });
   }
   if (memspace == BRBD_DEVICE) {
     hipStream_t st = (hipStream_t)stream;
@@ -1544,7 +1550,7 @@ int brbd_aba_derivatives(brbd_model* m, int64_t B, const double* q, int64_t ldq,
       acc = ctx->d_tmp;
       la = ld;
     }
-    return run(B, q, ldq, v, ldv, tau, ldtau, ddq_dq, lddq, ddq_dv, lddv, ddq_dtau, lddtau, acc, la, st);
+    return run(B, q, ldq, v, ldv, tau, ldtau, ddq_dq, lddq, ddq_dv, lddv, ddq_dtau, lddtau, acc, la, st, layout);
   }
   const HostMat mats[7] = {{q, nullptr, ldq, F.nq, true, false}, {v, nullptr, ldv, F.nv, true, false},
                            {tau, nullptr, ldtau, F.nv, true, false}, {nullptr, ddq_dq, lddq, nn, false, true},
@@ -1553,7 +1559,7 @@ int brbd_aba_derivatives(brbd_model* m, int64_t B, const double* q, int64_t ldq,
   return host_pipeline(m, B, layout, mats, 7, (hipStream_t)stream,
                        [&](int64_t Bc, double** d, const int64_t* ld, hipStream_t st) -> int {
                          return run(Bc, d[0], ld[0], d[1], ld[1], d[2], ld[2], d[3], ld[3], d[4], ld[4], d[5], ld[5],
-                                    d[6], ld[6], st);
+                                    d[6], ld[6], st, layout);
                        });
 }
 

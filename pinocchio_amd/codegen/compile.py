@@ -20,15 +20,17 @@ from typing import Dict, Optional
 import numpy as np
 
 from .. import model as M
-from . import aba, deriv, fkjac, joints, rnea
+from . import aba, deriv, fkjac, joints, minv, rnea
 from .emit import AHEAD, Emitter, plan_storage
 
-ALGOS = {"rnea": rnea.generate, "aba": aba.generate, "fkjac": fkjac.generate, "deriv": deriv.generate}
+ALGOS = {"rnea": rnea.generate, "aba": aba.generate, "fkjac": fkjac.generate, "deriv": deriv.generate,
+         "minv": minv.generate}
 
 # storage budgets (doubles per lane) of the park planner, per algorithm:
 # (registers for short-lived parks, LDS, registers for long-lived parks)
 # LDS: 160 KiB per CU, 4 resident waves of 64 lanes at one wave per SIMD -> 80 doubles per lane
-BUDGETS = {"rnea": (40, 80, 0), "aba": (48, 80, 100, 64), "fkjac": (36, 80, 0), "deriv": (64, 80, 32, 64)}  # (deriv: first rung of LADDER)
+BUDGETS = {"rnea": (40, 80, 0), "aba": (48, 80, 100, 64), "fkjac": (36, 80, 0), "deriv": (64, 80, 32, 64),
+           "minv": (64, 80, 64, 64)}  # (deriv: first rung of LADDER)
 for _a in list(BUDGETS):  # experiment hook: BRBD_CG_ABA="64,80"
     _v = os.environ.get("BRBD_CG_" + _a.upper())
     if _v:
@@ -37,7 +39,7 @@ for _a in list(BUDGETS):  # experiment hook: BRBD_CG_ABA="64,80"
 
 # prefetch distances that differ from emit.AHEAD (the derivative kernel's pair visits consume a
 # parked value every other statement: a long distance keeps hundreds of them in flight)
-AHEAD_ALGO = {"deriv": {"glb": 120, "in": 200}}
+AHEAD_ALGO = {"deriv": {"glb": 120, "in": 200}, "minv": {"glb": 120, "in": 200}}
 for _a in list(ALGOS):  # experiment hook: BRBD_CG_AHEAD_DERIV="glb=200,in=100"
     for _kv in os.environ.get("BRBD_CG_AHEAD_" + _a.upper(), "").split(","):
         if "=" in _kv:
@@ -45,7 +47,7 @@ for _a in list(ALGOS):  # experiment hook: BRBD_CG_AHEAD_DERIV="glb=200,in=100"
 
 
 # algorithms whose early loads are placed at statement granularity (emit.Emitter.text, ``fine``)
-FINE = set(os.environ.get("BRBD_CG_FINE", "deriv").split(","))
+FINE = set(os.environ.get("BRBD_CG_FINE", "deriv,minv").split(","))
 
 
 # Budget ladder: the budgets above suit the models they were tuned on; a larger model has enough
@@ -54,8 +56,9 @@ FINE = set(os.environ.get("BRBD_CG_FINE", "deriv").split(","))
 # scratch beyond ~200 doubles (512 registers per lane at one wave per SIMD, minus addressing).
 LADDER = {"aba": [(48, 80, 100, 64), (32, 80, 100, 64), (16, 80, 100, 64), (16, 80, 80, 64)],
           "deriv": [(64, 80, 32, 64), (40, 80, 32, 64), (24, 80, 16, 64), (8, 80, 0, 64), (0, 80, 0, 64),
-                    (0, 80, 0, 48), (0, 80, 0, 24)]}
-LIVE_MAX = {"aba": 230, "deriv": 182}
+                    (0, 80, 0, 48), (0, 80, 0, 24)],
+          "minv": [(64, 80, 64, 64), (32, 80, 32, 64), (16, 80, 16, 64), (0, 80, 0, 64)]}
+LIVE_MAX = {"aba": 230, "deriv": 182, "minv": 182}
 
 _IDENT = re.compile(r"\b([a-z][a-z]?_?[0-9]+(?:_[0-9]+)?|[sc]_t[0-9]+)\b")
 
@@ -106,7 +109,7 @@ def build_kernel(mv: joints.ModelView, algo: str, reg_budget: Optional[int] = No
         rt = budget[3] if len(budget) > 3 else 64
         rb = rb if reg_budget is None else reg_budget
         lb = lb if lds_budget is None else lds_budget
-        plan, lds, glb = plan_storage(dry.parks, rb, lb, rl, rt)
+        plan, lds, glb = plan_storage(dry.parks, rb, lb, rl, rt, strict=(algo == "minv"))
         e = gen(mv, Emitter(plan))
         text = e.text(ahead, algo in FINE)
         if len(ladder) == 1 or liveness_peak(text) <= LIVE_MAX[algo]:
@@ -133,6 +136,7 @@ _CPU_SHELL = r"""
 #define OUT2(k, val) out2[k] = (val)
 #define OUT3(k, val) out3[k] = (val)
 #define OUT4(k, val) out4[k] = (val)
+#define OUTSYM(k, val) out[k] = (WANT & 2) ? (val) : 0.0
 #ifdef SKIP_ZEROS
 #define OUTZ(k) do { } while (0)
 #define OUT2Z(k) do { } while (0)

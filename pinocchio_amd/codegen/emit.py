@@ -30,6 +30,7 @@ MACROS = """
   CT(k)                 k-th double of this kernel's packed constant table (wave-uniform -> s_load)
   IN_Q(k) IN_V(k) IN_X(k)   element k of q / v / third input (a or tau) of this lane's instance
   OUT(k, x)  OUT2(k, x)  OUT3(k, x)  store element k of the 1st / 2nd / 3rd output
+  OUTSYM(k, x)          element k of the 1st output, mirror image of a stored one (WANT bit 1: x, else 0)
   SINCOS(x, s, c)       s = sin(x), c = cos(x)
   RSQRT(x)  RCP(x)      1/sqrt(x), 1/x
   FMA(a, b, c)          a*b + c, one rounding
@@ -196,6 +197,12 @@ class Emitter:
         self.stmt("%s(%d, %s);" % (mac, k, x.code()))
         self.stats["st"] += 1
 
+    def out_sym(self, k: int, x: V):
+        """Element k of the first output as the mirror image of an element already written: stored
+        by the kernel variants with WANT bit 1 (symmetric fill), zero (or left alone) in the others."""
+        self.stmt("OUTSYM(%d, %s);" % (k, x.code()))
+        self.stats["st"] += 1
+
     def cond_sub(self, vals: Sequence[V], thunk, bit: int = 32) -> List[V]:
         """vals - thunk() in the kernel variants whose WANT mask has ``bit`` (external forces),
         vals unchanged in the others: the statements thunk() emits sit in an ``if (WANT & bit)``
@@ -340,6 +347,11 @@ class Emitter:
         return V(s), V(c)
 
     # ---- parking -------------------------------------------------------------------------------
+    tag_parks = False  # checker hook (tests/test_codegen_cpu.py): name the park behind every park access
+
+    def _tag(self, pk: "Park") -> str:
+        return " /*P%d*/" % pk.pid if Emitter.tag_parks else ""
+
     def park(self, vals: Sequence[V], hint: str = "stack") -> Park:
         """Hand values to the storage plan until a later visit asks for them back."""
         pk = Park(len(self.parks), list(vals), self.vi, hint)
@@ -352,7 +364,7 @@ class Emitter:
                 for j in range(0, len(live), 2):
                     a = live[j].name
                     b = live[j + 1].name if j + 1 < len(live) else a
-                    self.stmt("%s(%d, %s, %s);" % (mac, pk.slot // 2 + j // 2, a, b))
+                    self.stmt("%s(%d, %s, %s);%s" % (mac, pk.slot // 2 + j // 2, a, b, self._tag(pk)))
                     self.stats["st"] += 1
         return pk
 
@@ -382,7 +394,7 @@ class Emitter:
         for j in range(0, len(live), 2):
             a = self._tmp()
             b = self._tmp()
-            self.pre("double %s, %s; %s(%d, %s, %s);" % (a, b, mac, pk.slot // 2 + j // 2, a, b), pk.cls,
+            self.pre("double %s, %s; %s(%d, %s, %s);%s" % (a, b, mac, pk.slot // 2 + j // 2, a, b, self._tag(pk)), pk.cls,
                      pk.start + 1)
             self.stats["ld"] += 1
             names += [a, b]
@@ -493,7 +505,8 @@ class Emitter:
         return out
 
 
-def plan_storage(parks: Sequence[Park], reg_short: int, lds_budget: int, reg_long: int = 0, reg_tail: int = 64):
+def plan_storage(parks: Sequence[Park], reg_short: int, lds_budget: int, reg_long: int = 0, reg_tail: int = 64,
+                 strict: bool = False):
     """Assign every park a storage class: ("reg" | "lds" | "glb", first slot).
 
     * A park consumed by the very next visit stays in registers (chains hand state over for free).
@@ -505,7 +518,9 @@ def plan_storage(parks: Sequence[Park], reg_short: int, lds_budget: int, reg_lon
       AGPRs), then the LDS slots the stack leaves free during their lifetime, then global.
     LDS / global slots are allocated with interval first-fit at pair granularity; a slot may be
     reused by a park that starts in the visit its previous owner was last read in (those loads are
-    issued one visit earlier).  Returns (plan, lds_doubles, glb_doubles)."""
+    issued one visit earlier).  ``strict``: no such sharing of a visit -- for bodies that read a
+    park late in a visit in which they have already stored new ones (computeMinverse's backward
+    visits), with loads placed at statement granularity.  Returns (plan, lds_doubles, glb_doubles)."""
     plan: Dict[int, Tuple[str, int]] = {}
     used = {"lds": [], "glb": []}  # (slot, size, start, end)
     top = {"lds": 0, "glb": 0}
@@ -515,7 +530,10 @@ def plan_storage(parks: Sequence[Park], reg_short: int, lds_budget: int, reg_lon
         return n + (n & 1)
 
     def first_fit(cls, size, start, end, limit):
-        busy = sorted((s, sz) for s, sz, a, b in used[cls] if a < end and start < b)
+        if strict:
+            busy = sorted((s, sz) for s, sz, a, b in used[cls] if a <= end and start <= b)
+        else:
+            busy = sorted((s, sz) for s, sz, a, b in used[cls] if a < end and start < b)
         pos = 0
         for s, sz in busy:
             if pos + size <= s:

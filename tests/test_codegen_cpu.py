@@ -94,6 +94,56 @@ def test_derivative_body_under_the_prezeroed_contract():
         assert np.abs(x - r).max() / max(1.0, np.abs(r).max()) < 1e-12
 
 
+@pytest.mark.parametrize("model,dense", _models()[:3] + _models()[4:7], ids=lambda x: getattr(x, "name", str(x)))
+def test_generated_minverse_bodies_match_oracle(model, dense):
+    """codegen/minv.py (computeMinverse): the upper triangle like data.Minv (strictly lower part written as
+    zero), and the symmetric variant computeABADerivatives asks for; tiny budgets and the default ones."""
+    if not model.is_depth_first():
+        with pytest.raises(ValueError):
+            C.build_kernel(joints.ModelView(model, dense=dense), "minv")
+        return
+    mv = joints.ModelView(model, dense=dense)
+    q, _, _ = inputs(model, 6, 9)
+    nv = model.nv
+    ref = oracle.Oracle(model).minverse(q)
+    sym = ref.copy()
+    for b in range(q.shape[1]):
+        Mx = ref[:, b].reshape(nv, nv).T      # [row][col]
+        low = np.tril(Mx, -1)
+        full = Mx + np.where(low == 0.0, np.triu(Mx, 1).T, 0.0)   # (diagonal blocks of multi-dof joints are already full)
+        sym[:, b] = full.T.reshape(-1)
+    for want, kw, exp in ((1, dict(reg_budget=6, lds_budget=12), ref), (3, {}, sym)):
+        k = C.CpuKernel(mv, "minv", want=want, **kw)
+        t = k.kernel.text
+        assert t.count("OUT(") + t.count("OUTSYM(") + t.count("OUTZ(") == nv * nv   # every element exactly once
+        out = k.run(q, None, None, (nv * nv, 0, 0))[0]
+        assert np.abs(out - exp).max() / max(1.0, np.abs(exp).max()) < 1e-12
+
+
+@pytest.mark.parametrize("name,algo", [("quadruped", "minv"), ("simple_humanoid", "minv"), ("quadruped", "deriv"),
+                                       ("simple_humanoid", "aba"), ("talos_like", "aba"), ("simple_humanoid", "rnea")])
+def test_no_park_slot_is_read_after_another_park_took_it(name, algo):
+    """Every load of a parked value must see the slot still owned by that park: walks the emitted text
+    with the park behind every access named (Emitter.tag_parks) -- placement of early loads at
+    statement granularity and slot reuse within a visit are where this could go wrong."""
+    import re
+    emit.Emitter.tag_parks = True
+    try:
+        text = C.build_kernel(joints.ModelView(S.build(name)), algo).text
+    finally:
+        emit.Emitter.tag_parks = False
+    owner, n = {}, 0
+    for ln in text.splitlines():
+        for m_ in re.finditer(r"PK_(LDS|GLB)_(ST|LD)2\((\d+),[^;]*;\s*/\*P(\d+)\*/", ln):
+            slot, pid = (m_.group(1), int(m_.group(3))), int(m_.group(4))
+            if m_.group(2) == "ST":
+                owner[slot] = pid
+            else:
+                n += 1
+                assert owner.get(slot) == pid, ln
+    assert n > 0
+
+
 def test_fine_prefetch_placement_keeps_order():
     """Emitter.text(fine=True): every early load of a parked value comes after the park's stores
     and before its first use; the statements themselves keep their order."""

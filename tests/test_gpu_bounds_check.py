@@ -57,6 +57,11 @@ for name in ("simple_humanoid", "talos_like", "quadruped", "arm7", "manipulator"
                 if B <= 130 or name in ("quadruped", "arm7", "manipulator"):
                     parallel.computeRNEADerivatives(pool, qq, vv, aa, want_tau=True)
                     parallel.computeRNEADerivatives(pool, qq, vv, aa)
+                if dev and model.is_depth_first():   # compiled computeMinverse (BATCH_MAJOR) + the symmetric variant
+                    Mi = get(parallel.computeMinverse(pool, qq))
+                    assert np.abs(Mi - O.minverse(q)).max() / max(1.0, np.abs(Mi).max()) < 1e-10
+                    if B <= 130:
+                        parallel.computeABADerivatives(pool, qq, vv, tau)
     n = L.brbd_debug_oob_count(dm.handle)
     print(name, "out-of-range accesses:", n, flush=True)
     total += n

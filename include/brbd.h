@@ -130,7 +130,7 @@ int brbd_model_dims(const brbd_model* m, int32_t* njoints, int32_t* nq, int32_t*
  * (reported separately from algorithmic I/O in the roofline). */
 int64_t brbd_workspace_bytes(const brbd_model* m, int algo, int64_t B);
 enum brbd_algo { BRBD_ALGO_RNEA = 0, BRBD_ALGO_ABA = 1, BRBD_ALGO_FK_JAC = 2, BRBD_ALGO_RNEA_DERIV = 3,
-                 BRBD_ALGO_MINVERSE = 4 };
+                 BRBD_ALGO_MINVERSE = 4, BRBD_ALGO_ABA_DERIV_PRODUCTS = 5 };
 
 /* tau = RNEA(q, v, a) for B instances.
  * Replaces the loop body of rneaInParallel (algorithm/parallel/rnea.hpp:74-82)

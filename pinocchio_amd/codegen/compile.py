@@ -20,17 +20,17 @@ from typing import Dict, Optional
 import numpy as np
 
 from .. import model as M
-from . import aba, deriv, fkjac, joints, minv, rnea
+from . import aba, deriv, fkjac, joints, minv, prod, rnea
 from .emit import AHEAD, Emitter, plan_storage
 
 ALGOS = {"rnea": rnea.generate, "aba": aba.generate, "fkjac": fkjac.generate, "deriv": deriv.generate,
-         "minv": minv.generate}
+         "minv": minv.generate, "prod": prod.generate}
 
 # storage budgets (doubles per lane) of the park planner, per algorithm:
 # (registers for short-lived parks, LDS, registers for long-lived parks)
 # LDS: 160 KiB per CU, 4 resident waves of 64 lanes at one wave per SIMD -> 80 doubles per lane
 BUDGETS = {"rnea": (40, 80, 0), "aba": (48, 80, 100, 64), "fkjac": (36, 80, 0), "deriv": (64, 80, 32, 64),
-           "minv": (64, 80, 64, 64)}  # (deriv: first rung of LADDER)
+           "minv": (64, 80, 64, 64), "prod": (0, 0, 0)}  # (deriv: first rung of LADDER)
 for _a in list(BUDGETS):  # experiment hook: BRBD_CG_ABA="64,80"
     _v = os.environ.get("BRBD_CG_" + _a.upper())
     if _v:
@@ -39,7 +39,7 @@ for _a in list(BUDGETS):  # experiment hook: BRBD_CG_ABA="64,80"
 
 # prefetch distances that differ from emit.AHEAD (the derivative kernel's pair visits consume a
 # parked value every other statement: a long distance keeps hundreds of them in flight)
-AHEAD_ALGO = {"deriv": {"glb": 120, "in": 200}, "minv": {"glb": 120, "in": 200}}
+AHEAD_ALGO = {"deriv": {"glb": 120, "in": 200}, "minv": {"glb": 120, "in": 200}, "prod": {"in": 40}}
 for _a in list(ALGOS):  # experiment hook: BRBD_CG_AHEAD_DERIV="glb=200,in=100"
     for _kv in os.environ.get("BRBD_CG_AHEAD_" + _a.upper(), "").split(","):
         if "=" in _kv:
@@ -47,7 +47,7 @@ for _a in list(ALGOS):  # experiment hook: BRBD_CG_AHEAD_DERIV="glb=200,in=100"
 
 
 # algorithms whose early loads are placed at statement granularity (emit.Emitter.text, ``fine``)
-FINE = set(os.environ.get("BRBD_CG_FINE", "deriv,minv").split(","))
+FINE = set(os.environ.get("BRBD_CG_FINE", "deriv,minv,prod").split(","))
 
 
 # Budget ladder: the budgets above suit the models they were tuned on; a larger model has enough
@@ -137,6 +137,9 @@ _CPU_SHELL = r"""
 #define OUT3(k, val) out3[k] = (val)
 #define OUT4(k, val) out4[k] = (val)
 #define OUTSYM(k, val) out[k] = (WANT & 2) ? (val) : 0.0
+#define LD1(k) out[k]
+#define LD2(k) out2[k]
+#define LD3(k) out3[k]
 #ifdef SKIP_ZEROS
 #define OUTZ(k) do { } while (0)
 #define OUT2Z(k) do { } while (0)
@@ -194,7 +197,7 @@ class CpuKernel:
         dp, l = ctypes.POINTER(ctypes.c_double), ctypes.c_long
         self.lib.spec_batch.argtypes = [dp, l, dp, l, dp, l, dp, l, dp, l, dp, l, dp, l, dp, l, dp, l]
 
-    def run(self, q, v=None, x=None, out_rows=(0, 0, 0), fext=None):
+    def run(self, q, v=None, x=None, out_rows=(0, 0, 0), fext=None, init_outs=None):
         out_rows = tuple(out_rows) + (0,) * (4 - len(out_rows))
         def P(a):
             return None if a is None else a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
@@ -205,6 +208,9 @@ class CpuKernel:
         x = None if x is None else np.asfortranarray(x, dtype=np.float64)
         fext = None if fext is None else np.asfortranarray(fext, dtype=np.float64)
         outs = [np.zeros((r, B), order="F") if r else None for r in out_rows]
+        for o, src in zip(outs, init_outs or ()):  # (kernels that update their outputs in place)
+            if o is not None and src is not None:
+                o[...] = src
         self.lib.spec_batch(P(self.ct), B, P(q), q.shape[0], P(v), 0 if v is None else v.shape[0], P(x),
                             0 if x is None else x.shape[0], P(outs[0]), out_rows[0], P(outs[1]), out_rows[1],
                             P(outs[2]), out_rows[2], P(outs[3]), out_rows[3], P(fext),

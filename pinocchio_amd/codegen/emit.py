@@ -30,6 +30,7 @@ MACROS = """
   CT(k)                 k-th double of this kernel's packed constant table (wave-uniform -> s_load)
   IN_Q(k) IN_V(k) IN_X(k)   element k of q / v / third input (a or tau) of this lane's instance
   OUT(k, x)  OUT2(k, x)  OUT3(k, x)  store element k of the 1st / 2nd / 3rd output
+  LD1(k) LD2(k) LD3(k)  element k of the 1st / 2nd / 3rd output matrix, read (in-place kernels)
   OUTSYM(k, x)          element k of the 1st output, mirror image of a stored one (WANT bit 1: x, else 0)
   SINCOS(x, s, c)       s = sin(x), c = cos(x)
   RSQRT(x)  RCP(x)      1/sqrt(x), 1/x
@@ -191,6 +192,18 @@ class Emitter:
         v = V(name)
         self.in_cache[key] = v
         return v
+
+    def inp_out(self, which: int, k: int) -> V:
+        """Element k of output matrix `which` as an INPUT (kernels that update a matrix in place or
+        read a third one): a fresh load every time it is asked for."""
+        name = "ld%d_%d" % (self._next_io(), which)  # (shape of the names the text passes look for)
+        self.pre("const double %s = LD%d(%d);" % (name, which, k), "in")
+        self.stats["ld"] += 1
+        return V(name)
+
+    def _next_io(self) -> int:
+        self.n_io = getattr(self, "n_io", 0) + 1
+        return self.n_io
 
     def out(self, k: int, x: V, which: int = 1):
         mac = "OUT" if which == 1 else "OUT%d" % which

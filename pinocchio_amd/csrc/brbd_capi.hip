@@ -96,14 +96,14 @@ struct brbd_model {
   unsigned long long* d_oob = nullptr;  // checking build: out-of-range access counter of the compiled kernels
   double* scratch = nullptr;  // this device's copy of the file-scope scratch array (brbd_aba_noalloc)
   // per-algorithm launch geometry (waves resident on the device)
-  int max_waves[5] = {0, 0, 0, 0, 0};
-  int max_waves_spec[5] = {0, 0, 0, 0, 0};
+  int max_waves[6] = {0, 0, 0, 0, 0, 0};
+  int max_waves_spec[6] = {0, 0, 0, 0, 0, 0};
   int max_waves_jjac = 0;
   int max_waves_f4[4] = {0, 0, 0, 0};  // minverse, integrate, aba-derivative products (nv <= 24, nv <= 48)
   std::map<int, std::pair<Op*, int>> chains;  // brbd_joint_jacobian: support chain of a joint (device)
   // model-compiled kernels (brbd_spec.hpp), when the model's signature is registered
   const SpecEntry* spec = nullptr;
-  double* d_ct[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // packed constant table per algorithm
+  double* d_ct[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // packed constant table per algorithm
   bool prezeroed = false;  // brbd_model_outputs_prezeroed: derivative kernels skip structural zeros
   bool use_spec = true;  // BRBD_DISABLE_COMPILED=1 or brbd_model_use_compiled(m, 0): table-driven kernels
   bool use_lds = true;
@@ -111,7 +111,7 @@ struct brbd_model {
   int timing = 0;  // 0 off, 1 two events per launch, 2 chained (one event per launch)
   std::shared_ptr<Ev> last_stop;
   hipStream_t last_stream = nullptr;
-  std::vector<TimedLaunch> timed[5];
+  std::vector<TimedLaunch> timed[6];
   std::mutex mu;
 };
 
@@ -318,6 +318,7 @@ int launch_algo(brbd_model* m, int algo, KArgs& A, int layout, hipStream_t strea
     case BRBD_ALGO_FK_JAC: per_lane = F.ws_fkjac(); break;
     case BRBD_ALGO_RNEA_DERIV: per_lane = 1; break;  // (only reached when a compiled kernel exists)
     case BRBD_ALGO_MINVERSE: per_lane = 1; break;    // (likewise)
+    case BRBD_ALGO_ABA_DERIV_PRODUCTS: per_lane = 1; break;
     default: return fail(BRBD_ERR_INVALID_ARGUMENT, "unknown algorithm");
   }
   // model-compiled kernel?  (BATCH_MAJOR addresses elements with 32-bit byte offsets)
@@ -330,7 +331,7 @@ int launch_algo(brbd_model* m, int algo, KArgs& A, int layout, hipStream_t strea
     else variant = A.fext ? 1 : 0;  // rnea / aba: kernel variant with external forces
     // buffer ranges: every matrix must span less than 4 GiB (32-bit byte offsets)
     const int64_t nn = (int64_t)F.nv * F.nv;
-    const bool der = algo == BRBD_ALGO_RNEA_DERIV || algo == BRBD_ALGO_MINVERSE;
+    const bool der = algo == BRBD_ALGO_RNEA_DERIV || algo == BRBD_ALGO_MINVERSE || algo == BRBD_ALGO_ABA_DERIV_PRODUCTS;
     const int64_t dofs[8] = {F.nq, F.nv, F.nv, der ? nn : (algo == BRBD_ALGO_FK_JAC ? 6 * (int64_t)F.nv : F.nv),
                              der ? nn : 12 * (int64_t)F.njoints, nn, F.nv, 6 * (int64_t)F.njoints};
     const void* ptrs[8] = {A.q, A.v, A.a, A.out, A.out2, A.out3, A.out4, A.fext};
@@ -361,7 +362,7 @@ int launch_algo(brbd_model* m, int algo, KArgs& A, int layout, hipStream_t strea
       klayout = 2;
     if (sk && !sk->fn[klayout][variant]) sk = nullptr;
   }
-  if ((algo == BRBD_ALGO_RNEA_DERIV || algo == BRBD_ALGO_MINVERSE) && !sk) return 1;  // caller falls back to the table-driven kernel
+  if ((algo == BRBD_ALGO_RNEA_DERIV || algo == BRBD_ALGO_MINVERSE || algo == BRBD_ALGO_ABA_DERIV_PRODUCTS) && !sk) return 1;  // caller falls back to the table-driven kernel
   const bool stat = sk != nullptr;
   SpecFn sfn = stat ? sk->fn[klayout][variant] : nullptr;
   const int stage = stat && klayout == 2 ? sk->stage_doubles : 0;
@@ -623,7 +624,7 @@ int brbd_model_create(const brbd_model_desc* desc, int device, brbd_model** out)
       for (size_t k = 0; k < g_plugin_entries.size() && !m->spec; ++k)
         if ((pass == 0 ? exact : dense) == g_plugin_entries[k]->signature) m->spec = g_plugin_entries[k];
     }
-    for (int a = 0; m->spec && a < 5 && e == hipSuccess; ++a) {
+    for (int a = 0; m->spec && a < 6 && e == hipSuccess; ++a) {
       const std::vector<double> ct = pack_constants(m->flat, m->spec->algo[a]);
       e = upload((void**)&m->d_ct[a], ct.data(), ct.size() * sizeof(double));
     }
@@ -1523,6 +1524,13 @@ int brbd_aba_derivatives(brbd_model* m, int64_t B, const double* q, int64_t ldq,
       if ((r = deriv_device(m, Bc, in, ldi, out, ldo, st, layout, 0))) return r;
     }
     if ((r = minverse_device(m, Bc, dq, l0, o3, lo3, 1, layout, st))) return r;
+    if (m->spec && m->use_spec && layout == BRBD_BATCH_MAJOR) {  // model-compiled products (codegen/prod.py)
+      KArgs K{};
+      fill_common(m, K, Bc);
+      K.out = o1; K.ldout = lo1; K.out2 = o2; K.ldout2 = lo2; K.out3 = o3; K.ldout3 = lo3;
+      r = launch_algo(m, BRBD_ALGO_ABA_DERIV_PRODUCTS, K, layout, st);
+      if (r <= 0) return r;  // 1 = no compiled kernel applies
+    }
     F4Args A{};
     fill_f4(m, A, Bc);
     A.out = o1; A.ldout = lo1; A.out2 = o2; A.ldout2 = lo2; A.minv = o3; A.ldminv = lo3;
@@ -1697,7 +1705,7 @@ int brbd_set_timing(brbd_model* m, int enabled) {
 }
 
 int brbd_kernel_time(brbd_model* m, int algo, int32_t* launches, double* total_ms) {
-  if (!m || algo < 0 || algo > 4) return fail(BRBD_ERR_INVALID_ARGUMENT, "bad model handle or algo");
+  if (!m || algo < 0 || algo > 5) return fail(BRBD_ERR_INVALID_ARGUMENT, "bad model handle or algo");
   DevGuard dg(m->device);
   std::vector<TimedLaunch> v;
   {

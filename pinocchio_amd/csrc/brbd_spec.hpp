@@ -37,12 +37,12 @@ enum : int { SF_R = 0, SF_T, SF_M, SF_C, SF_I, SF_ARM, SF_AXIS, SF_G };
 // Layout version of KArgs / SpecKernel / SpecEntry: kernels compiled separately (plugins built by
 // pinocchio_amd/codegen/plugin.py for models unknown when the library was built, loaded with
 // brbd_load_compiled_kernels) must agree with the library that launches them.
-#define BRBD_SPEC_ABI 4
+#define BRBD_SPEC_ABI 5
 
 struct SpecEntry {
   const char* name;
   const char* signature;  // tree + joint kinds + 0/1/-1 pattern of the constants (codegen/joints.py)
-  SpecKernel algo[5];     // BRBD_ALGO_RNEA, _ABA, _FK_JAC, _RNEA_DERIV, _MINVERSE
+  SpecKernel algo[6];     // BRBD_ALGO_RNEA, _ABA, _FK_JAC, _RNEA_DERIV, _MINVERSE, _ABA_DERIV_PRODUCTS
 };
 
 // ---- memory access of the model-compiled kernels ------------------------------------------------
@@ -292,6 +292,10 @@ DI void spec_sincos(double x, double& so, double& co) {
 #define IN_F(k) ((WANT & 32) ? mf.get(k, ldf8) : 0.0)
 #define OUT(k, val) do { if (WANT & 1) mo.put(k, ldo8, val); } while (0)
 #define OUT2(k, val) do { if (WANT & 2) mo2.put(k, ldo28, val); } while (0)
+// output matrices read (kernels that update them in place, or read the third one: codegen/prod.py)
+#define LD1(k) (mo.get(k, ldo8))
+#define LD2(k) (mo2.get(k, ldo28))
+#define LD3(k) (mo3.get(k, ldo38))
 // mirror image of an element of the first output (computeMinverse: the strictly lower triangle):
 // the value in the variants with WANT bit 1, a structural zero in the others
 #define OUTSYM(k, val) do { if (WANT & 2) mo.put(k, ldo8, val); else if ((WANT & 17) == 17) mo.put(k, ldo8, 0.0); } while (0)

@@ -120,6 +120,34 @@ def test_generated_minverse_bodies_match_oracle(model, dense):
         assert np.abs(out - exp).max() / max(1.0, np.abs(exp).max()) < 1e-12
 
 
+@pytest.mark.parametrize("model", [S.quadruped(), S.arm7(), S.baxter_simple(),
+                                   S.random_tree(301, 9, root_kind=M.JOINT_FREEFLYER, armature=True)],
+                         ids=lambda x: getattr(x, "name", str(x)))
+def test_generated_product_bodies_match_numpy(model):
+    """codegen/prod.py (the closing products of computeABADerivatives, in place): -Minv dtau/dq and
+    -Minv dtau/dv from the oracle's matrices; both strategies (Minv in registers / column groups)."""
+    mv = joints.ModelView(model)
+    nv = model.nv
+    nn = nv * nv
+    q, v, a = inputs(model, 5, 11)
+    O = oracle.Oracle(model)
+    dq, dv = O.rnea_derivatives(q, v, a)[:2]
+    Mf = O.minverse(q)
+    exp1, exp2 = np.zeros_like(dq), np.zeros_like(dv)
+    for b in range(q.shape[1]):
+        X = Mf[:, b].reshape(nv, nv).T
+        X = np.triu(X) + np.triu(X, 1).T
+        Mf[:, b] = X.T.reshape(-1)
+        exp1[:, b] = (-X @ dq[:, b].reshape(nv, nv).T).T.reshape(-1)
+        exp2[:, b] = (-X @ dv[:, b].reshape(nv, nv).T).T.reshape(-1)
+    k = C.CpuKernel(mv, "prod", want=3)
+    assert k.kernel.lds == 0 and k.kernel.glb == 0
+    o1, o2, o3 = k.run(q, None, None, (nn, nn, nn), init_outs=(dq, dv, Mf))[:3]
+    assert np.abs(o1 - exp1).max() <= 1e-12 * np.abs(exp1).max()
+    assert np.abs(o2 - exp2).max() <= 1e-12 * np.abs(exp2).max()
+    assert np.array_equal(o3, Mf)   # Minv is only read
+
+
 @pytest.mark.parametrize("name,algo", [("quadruped", "minv"), ("simple_humanoid", "minv"), ("quadruped", "deriv"),
                                        ("simple_humanoid", "aba"), ("talos_like", "aba"), ("simple_humanoid", "rnea")])
 def test_no_park_slot_is_read_after_another_park_took_it(name, algo):

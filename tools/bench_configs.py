@@ -4,7 +4,7 @@ library's hipEvents: [1] arm7 FK + Jacobians B=1M, [3] talos-class ABA B=1M (one
 8M), [4] quadruped RNEA derivatives B=262144.  Prints one JSON line per config."""
 import json, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import numpy as np, torch   # (oracle: only to count the structural non-zeros of one instance, below)
 from pinocchio_amd import capi, parallel, sample_models as S
 
 def inputs(m, B):
@@ -65,8 +65,14 @@ if "deriv" in which:
     # the reference's contract: outputs zeroed by the caller, structural zeros not rewritten
     outs = [torch.zeros((m.nv * m.nv, B), dtype=torch.float64, device="cuda") for _ in range(3)]
     t = timed(dm, capi.ALGO_RNEA_DERIV, lambda: parallel.computeRNEADerivatives(pool, q, v, a, out=outs), 5)
+    # priced with the bytes this variant moves: the structural zeros are neither read nor written
+    import oracle as _oracle
+    rng1 = np.random.default_rng(5)
+    nz = sum(int(np.count_nonzero(x)) for x in _oracle.Oracle(m).rnea_derivatives(
+        m.random_configuration(rng1, 1), rng1.uniform(-1, 1, (m.nv, 1)), rng1.uniform(-1, 1, (m.nv, 1)))[:3])
+    byts_pz = ((m.nq + 2 * m.nv) + nz) * 8 * B
     print(json.dumps({"config": "quadruped RNEA derivatives B=262144, outputs pre-zeroed by the caller",
-                      "s_per_call": t, "evals_per_s": B / t, "GBps_algorithmic": byts / t / 1e9}))
+                      "s_per_call": t, "evals_per_s": B / t, "stores_per_eval": nz, "GBps_moved": byts_pz / t / 1e9}))
     pool.release()
 
 if "fext" in which:   # simple_humanoid with external forces (rnea.hxx:171-219, aba.hxx:296-354)

@@ -48,7 +48,14 @@ class ModelPool:
     of Model and Data, one per OpenMP thread; here the replicas are one flattened BatchModel
     per GPU, created lazily, and ``size`` only drives the reference's argument checks."""
 
-    def __init__(self, model: Model, pool_size: Optional[int] = None):
+    def __init__(self, model: Model, pool_size: Optional[int] = None, compile_kernels: bool = False,
+                 plugin_cache: Optional[str] = None):
+        """``compile_kernels``: a model the library has no compiled kernels for gets them from the
+        plugin cache (``plugin_cache``, $BRBD_PLUGIN_CACHE, ~/.cache/brbd_plugins), built on first use
+        with hipcc (codegen/plugin.py: minutes for a humanoid); off by default -- such a model then
+        runs on the table-driven kernels."""
+        self._compile = bool(compile_kernels)
+        self._plugin_cache = plugin_cache
         if pool_size is None:
             pool_size = omp_get_max_threads()  # pool/model.hpp:41
         if pool_size < 0:
@@ -90,6 +97,13 @@ class ModelPool:
         d = self._dev.get(key)
         if d is None:
             d = capi.DeviceModel(self._model, device)
+            if self._compile and d.compiled_kernels() == "":
+                from .codegen import plugin
+                path = plugin.cached_plugin(self._model, self._plugin_cache)
+                if path is not None:
+                    capi.load_compiled_kernels(path)
+                    d.close()
+                    d = capi.DeviceModel(self._model, device)
             self._dev[key] = d
         return d
 

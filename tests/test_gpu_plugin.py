@@ -64,3 +64,35 @@ def test_plugin_kernels_for_a_model_unknown_at_build_time():
                                                                 "plugin": PLUGIN}],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "PLUGIN-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+CACHE = os.path.join(ROOT, "pinocchio_amd", "plugins", "cache")
+SCRIPT_CACHE = r"""
+import sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)
+import numpy as np
+import oracle
+from pinocchio_amd import parallel, sample_models as S
+from pinocchio_amd.codegen import plugin
+from util import inputs, rel_err_cols
+m = S.random_tree(7, 4)
+assert plugin.cached_plugin(m, %(cache)r, build_missing=False) is not None, "run __graft_entry__.build()"
+pool = parallel.ModelPool(m, 1)
+assert pool.device_model(0).compiled_kernels() == ""
+pool.release()
+pool = parallel.ModelPool(m, 1, compile_kernels=True, plugin_cache=%(cache)r)     # cache hit: nothing is compiled here
+assert pool.device_model(0).compiled_kernels().startswith("m_")
+q, v, a = inputs(m, 300, 4)
+O = oracle.Oracle(m)
+tau = parallel.rneaInParallel(1, pool, q, v, a)
+assert rel_err_cols(tau, O.rnea(q, v, a)).max() < 1e-12
+assert rel_err_cols(parallel.abaInParallel(1, pool, q, v, tau), a).max() < 1e-10
+print("CACHE-OK")
+"""
+
+
+def test_model_pool_takes_compiled_kernels_from_the_plugin_cache():
+    r = subprocess.run([sys.executable, "-u", "-c", SCRIPT_CACHE % {"root": ROOT, "tests": os.path.join(ROOT, "tests"),
+                                                                      "cache": CACHE}],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "CACHE-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

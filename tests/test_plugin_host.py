@@ -38,3 +38,18 @@ def test_a_urdf_with_a_fixed_base_is_a_different_kernel_set():
         fixed = U.build_model_from_urdf(f.read(), free_flyer=False)
     assert fixed.nq == 29 and fixed.nv == 29
     assert joints.ModelView(fixed).signature() != joints.ModelView(S.simple_humanoid()).signature()
+
+
+def test_plugin_cache_builds_once_and_keys_on_the_signature(tmp_path):
+    """codegen/plugin.cached_plugin: the first request builds (a 4-joint tree: seconds), the second is a
+    cache hit; another robot of the same kind (same signature) shares the entry, another tree does not."""
+    from pinocchio_amd import model as M, sample_models as S
+    from pinocchio_amd.codegen import plugin
+    m1 = S.random_tree(7, 4)
+    cache = str(tmp_path / "cache")
+    assert plugin.cached_plugin(m1, cache, build_missing=False) is None
+    p1 = plugin.cached_plugin(m1, cache)
+    assert p1 is not None and os.path.exists(p1)
+    t = os.path.getmtime(p1)
+    assert plugin.cached_plugin(m1, cache) == p1 and os.path.getmtime(p1) == t
+    assert plugin.cache_key(S.random_tree(8, 4)) != plugin.cache_key(m1)

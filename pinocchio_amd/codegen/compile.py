@@ -58,7 +58,7 @@ LADDER = {"aba": [(48, 80, 100, 64), (32, 80, 100, 64), (16, 80, 100, 64), (16, 
           "deriv": [(64, 80, 32, 64), (40, 80, 32, 64), (24, 80, 16, 64), (8, 80, 0, 64), (0, 80, 0, 64),
                     (0, 80, 0, 48), (0, 80, 0, 24)],
           "minv": [(64, 80, 64, 64), (32, 80, 32, 64), (16, 80, 16, 64), (0, 80, 0, 64)]}
-LIVE_MAX = {"aba": 230, "deriv": 182, "minv": 182}
+LIVE_MAX = {"aba": 230, "deriv": 182, "minv": 200}
 
 _IDENT = re.compile(r"\b([a-z][a-z]?_?[0-9]+(?:_[0-9]+)?|[sc]_t[0-9]+)\b")
 

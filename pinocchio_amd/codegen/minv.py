@@ -19,9 +19,10 @@ as parks of 6 * nv_j doubles, one per (block owner, joint j whose dofs are the c
   the tree (:819-825: also the columns right of i's subtree, which pass 2 left at zero), then
   F_i[j] = F_parent[j] + J Minv(i, j) for the joints j that i's children will ask for (:827-832).
 
-One sub-visit per (i, j): the work per column is independent, so nothing but the joint's own
-U / UDinv / J has to stay in registers across them.  Needs depth-first numbering (every subtree's
-dofs contiguous), like the derivatives.
+The work per column is independent.  Pass 2 takes one sub-visit per (i, j) with the joint's own
+U / UDinv / J in registers; pass 3 walks a whole chain of single-child joints (a limb) per column
+block, so a column of F is read once per limb and parked again only where the tree branches.
+Needs depth-first numbering (every subtree's dofs contiguous), like the derivatives.
 """
 from __future__ import annotations
 
@@ -158,52 +159,67 @@ def generate(mv: J.ModelView, e: Emitter) -> Emitter:
             st = e.unpark(kin[i])
             backward(i, [st[0:3], st[3:6], st[6:9]], st[9:12])
 
-    # ---- pass 3 (:802-833), parents before children
-    for i in range(1, n):
-        p = mv.parents[i]
-        if p == 0:
+    # ---- pass 3 (:802-833), parents before children.  A chain of joints with one child each (a limb)
+    # is walked per COLUMN BLOCK: the block's F column comes in once from the chain's parent, every
+    # joint of the chain updates its rows of Minv and the column in registers, and the column is
+    # parked again only below the chain's last joint if that one branches.  (Joint by joint, every
+    # joint of a limb would read and write the F columns of everything to its right.)
+    CHAIN_MAX = 8
+    done = set()
+    for i0 in range(1, n):
+        if mv.parents[i0] == 0 or i0 in done:
             continue
-        nv, iv = mv.nv(i), mv.idx_v[i]
-        tree_last = i
-        r_ = i
+        chain = [i0]
+        while len(mv.children[chain[-1]]) == 1 and len(chain) < CHAIN_MAX:
+            chain.append(mv.children[chain[-1]][0])
+        done.update(chain)
+        p = mv.parents[i0]
+        r_ = i0
         while mv.parents[r_] > 0:
             r_ = mv.parents[r_]
         tree_last = last[r_]
-        e.begin_visit("PASS3 %d" % i)
-        h = e.unpark(hand[i])
-        UD = [h[6 * k:6 * k + 6] for k in range(nv)]
-        Jc = [h[6 * nv + 6 * k:6 * nv + 6 * k + 6] for k in range(nv)]
-        mr = e.unpark(mrow[i])
-        pos = {}
-        off = 0
-        for j in range(i, last[i] + 1):  # order of `keep`: own block first, then the joints below
-            pos[j] = off
-            off += nv * mv.nv(j)
+        tail = chain[-1]
+        e.begin_visit("PASS3 %d..%d" % (i0, tail))
+        UD, Jc, mr, pos = {}, {}, {}, {}
+        for i in chain:
+            nv = mv.nv(i)
+            h = e.unpark(hand[i])
+            UD[i] = [h[6 * k:6 * k + 6] for k in range(nv)]
+            Jc[i] = [h[6 * nv + 6 * k:6 * nv + 6 * k + 6] for k in range(nv)]
+            mr[i] = e.unpark(mrow[i])
+            pos[i], off = {}, 0
+            for j in range(i, last[i] + 1):  # order of `keep`: own block first, then the joints below
+                pos[i][j] = off
+                off += nv * mv.nv(j)
         fout = {}
         first = True
-        for j in range(i, tree_last + 1):
+        for j in range(i0, tree_last + 1):
             if not first:
-                e.begin_visit("PASS3 %d x %d" % (i, j))
+                e.begin_visit("PASS3 %d..%d x %d" % (i0, tail, j))
             first = False
-            fp = e.unpark(f3[p][j])
-            want_f = bool(mv.children[i]) and j > i
+            fcols = e.unpark(f3[p][j])
+            want_f = bool(mv.children[tail]) and j > tail
             fnew = []
             for k, cj in enumerate(cols(j)):
-                fc = fp[6 * k:6 * k + 6]
-                x = []
-                for r in range(nv):
-                    base = mr[pos[j] + k * nv + r] if j <= last[i] else ZERO
-                    x.append(e.sub(base, A.dot6(e, UD[r], fc)))                  # :819-825
-                    put(iv + r, cj, x[r], j != i)
-                if want_f:
-                    g = fc
+                fc = fcols[6 * k:6 * k + 6]
+                for i in chain:
+                    if j < i:      # (columns left of joint i: not its business, nor its successors')
+                        break
+                    nv, iv = mv.nv(i), mv.idx_v[i]
+                    x = []
                     for r in range(nv):
-                        g = A.vaxpy(e, x[r], Jc[r], g)                           # :827-832
-                    fnew += g
+                        base = mr[i][pos[i][j] + k * nv + r] if j <= last[i] else ZERO
+                        x.append(e.sub(base, A.dot6(e, UD[i][r], fc)))           # :819-825
+                        put(iv + r, cj, x[r], j != i)
+                    if i != tail or want_f:
+                        for r in range(nv):
+                            fc = A.vaxpy(e, x[r], Jc[i][r], fc)                  # :827-832
+                if want_f:
+                    fnew += fc
             if want_f:
                 fout[j] = e.park(fnew, "stack")
         if fout:
-            f3[i] = fout
+            f3[tail] = fout
     # everything else is structurally zero: other trees, and (unless mirrored) the strictly lower part
     for cc in range(nvt):
         for r in range(nvt):

@@ -360,6 +360,10 @@ int launch_algo(brbd_model* m, int algo, KArgs& A, int layout, hipStream_t strea
     if (sk && layout == BRBD_INSTANCE_MAJOR && !no_staged && (algo == BRBD_ALGO_RNEA || algo == BRBD_ALGO_ABA) &&
         sk->fn[2][variant] && A.ldq == F.nq && A.ldv == F.nv && A.lda == F.nv && A.ldout == F.nv)
       klayout = 2;
+    // (forward kinematics + Jacobians: q staged in, the 6 nv rows of J collected and transposed out)
+    if (sk && layout == BRBD_INSTANCE_MAJOR && !no_staged && algo == BRBD_ALGO_FK_JAC && sk->fn[2][variant] &&
+        A.ldq == F.nq && A.ldout == 6 * (int64_t)F.nv)
+      klayout = 2;
     if (sk && !sk->fn[klayout][variant]) sk = nullptr;
   }
   if ((algo == BRBD_ALGO_RNEA_DERIV || algo == BRBD_ALGO_MINVERSE || algo == BRBD_ALGO_ABA_DERIV_PRODUCTS) && !sk) return 1;  // caller falls back to the table-driven kernel

@@ -51,8 +51,10 @@ for name in ("simple_humanoid", "talos_like", "quadruped", "arm7", "manipulator"
                 assert rel_err_cols(get(ddq), a).max() < 1e-10
                 tf = parallel.rnea(pool, qq, vv, aa, ff)
                 assert rel_err_cols(get(parallel.aba(pool, qq, vv, tf, ff)), a).max() < 1e-10
-                parallel.computeJointJacobians(pool, qq, want_oMi=True)
-                parallel.computeJointJacobians(pool, qq)
+                Jr, Mr = O.fk_jacobians(q)
+                J2, M2 = parallel.computeJointJacobians(pool, qq, want_oMi=True)
+                assert np.abs(get(J2) - Jr).max() < 1e-12 and np.abs(get(M2) - Mr).max() < 1e-12
+                assert np.abs(get(parallel.computeJointJacobians(pool, qq)) - Jr).max() < 1e-12   # (layout 2 when staged)
                 parallel.forwardKinematics(pool, qq)
                 if B <= 130 or name in ("quadruped", "arm7", "manipulator"):
                     parallel.computeRNEADerivatives(pool, qq, vv, aa, want_tau=True)

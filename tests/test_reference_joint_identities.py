@@ -1,0 +1,119 @@
+"""The reference's per-joint unit tests that compare a joint with the matching rows of a free-flyer
+(no stored numbers: identities between two models) -- unittest/joint-spherical.cpp:52-141
+(JointModelSpherical vs the angular half of a free-flyer) and unittest/joint-prismatic.cpp /
+joint-translation.cpp in the same style for PX / PY / PZ vs the linear half.  The free-flyer is the
+root of the value-pinned humanoid (tests/test_reference_values.py), so these tie the spherical and
+prismatic code to it.  Same models, inputs and checks as the reference; on the CPU for the oracle,
+with `-m gpu` for the HIP path through the C ABI (table-driven: these one-joint models have no
+compiled kernels)."""
+import numpy as np
+import pytest
+
+import oracle
+from pinocchio_amd import capi, model as M, parallel
+
+TOL = 1e-12
+
+
+def _one_joint(jtype, name):
+    m = M.Model(name)
+    P = np.eye(4)
+    P[:3, 3] = (1.0, 0.0, 0.0)                                        # joint-spherical.cpp:61-62
+    j = m.addJoint(0, jtype, P, name)
+    m.appendBodyToJoint(j, M.Inertia(1.0, (0.5, 0.0, 0.0), np.eye(3)))  # :60
+    return m
+
+
+def _mass_matrix(dtau_da, nv):
+    Mu = np.triu(dtau_da.reshape(nv, nv).T)   # (upper triangle, column-major per instance)
+    return Mu + np.triu(Mu, 1).T
+
+
+class _OracleBackend:
+    def __init__(self, model):
+        self.O, self.nv = oracle.Oracle(model), model.nv
+
+    def rnea(self, q, v, a):
+        return self.O.rnea(q, v, a)[:, 0]
+
+    def aba(self, q, v, tau):
+        return self.O.aba(q, v, tau)[:, 0]
+
+    def M(self, q, v, a):
+        return _mass_matrix(self.O.rnea_derivatives(q, v, a)[2][:, 0], self.nv)
+
+    def J_local(self, q):
+        return self.O.joint_jacobian(q, 1, capi.LOCAL)[:, 0].reshape(self.nv, 6).T
+
+
+class _GpuBackend:
+    def __init__(self, model):
+        self.pool, self.nv = parallel.ModelPool(model, 1), model.nv
+
+    def rnea(self, q, v, a):
+        return parallel.rneaInParallel(1, self.pool, q, v, a)[:, 0]
+
+    def aba(self, q, v, tau):
+        return parallel.abaInParallel(1, self.pool, q, v, tau)[:, 0]
+
+    def M(self, q, v, a):
+        return _mass_matrix(parallel.computeRNEADerivatives(self.pool, q, v, a)[2][:, 0], self.nv)
+
+    def J_local(self, q):
+        return parallel.getJointJacobian(self.pool, q, 1, capi.LOCAL)[:, 0].reshape(self.nv, 6).T
+
+
+def _col(*x):
+    return np.asarray(x, dtype=np.float64).reshape(-1, 1)
+
+
+def _check_spherical(Backend):
+    sph, ff = Backend(_one_joint(M.JOINT_SPHERICAL, "spherical")), Backend(_one_joint(M.JOINT_FREEFLYER, "free-flyer"))
+    q = np.ones(4) / 2.0                                              # :71-72 Ones, normalized
+    qff = _col(0, 0, 0, *q)                                           # :73-74
+    q = q.reshape(4, 1)
+    v, vff = _col(1, 1, 1), _col(0, 0, 0, 1, 1, 1)                    # :75-77
+    a, aff = v.copy(), vff.copy()                                     # :83-84
+    tau, tauff = sph.rnea(q, v, a), ff.rnea(qff, vff, aff)            # :104-105
+    assert np.allclose(tau, tauff[3:], rtol=TOL, atol=0)              # :107-109
+    a_s = sph.aba(q, v, tau.reshape(3, 1))                            # :112-113
+    a_f = ff.aba(qff, vff, tauff.reshape(6, 1))                       # :114-115
+    assert np.allclose(a_s, a_f[3:], rtol=1e-10, atol=0) and np.allclose(a_s, 1.0, rtol=1e-10)   # :116-118
+    assert np.allclose(sph.M(q, v, a), ff.M(qff, vff, aff)[3:, 3:], rtol=TOL, atol=1e-14)       # :121-126
+    assert np.allclose(sph.J_local(q), ff.J_local(qff)[:, 3:], rtol=TOL, atol=1e-14)            # :129-140
+
+
+def _check_prismatic(Backend, jtype, k):
+    """PX / PY / PZ against column k of the free-flyer at the identity orientation
+    (joint-prismatic.cpp:62-135 compares with a free-flyer through an `expected` built this way)."""
+    pr, ff = Backend(_one_joint(jtype, "prismatic")), Backend(_one_joint(M.JOINT_FREEFLYER, "free-flyer"))
+    q, qff = _col(0.7), np.zeros((7, 1))
+    qff[k, 0], qff[6, 0] = 0.7, 1.0
+    v, a = _col(1.0), _col(1.0)
+    vff, aff = np.zeros((6, 1)), np.zeros((6, 1))
+    vff[k, 0] = aff[k, 0] = 1.0
+    tau, tauff = pr.rnea(q, v, a), ff.rnea(qff, vff, aff)
+    assert np.allclose(tau, tauff[k], rtol=TOL, atol=1e-14)
+    assert np.allclose(pr.M(q, v, a), ff.M(qff, vff, aff)[k, k], rtol=TOL)
+    assert np.allclose(pr.J_local(q)[:, 0], ff.J_local(qff)[:, k], rtol=TOL, atol=1e-14)
+    assert np.allclose(pr.aba(q, v, tau.reshape(1, 1)), 1.0, rtol=1e-10)
+
+
+def test_spherical_joint_is_the_angular_half_of_a_free_flyer_oracle():
+    _check_spherical(_OracleBackend)
+
+
+@pytest.mark.parametrize("jtype,k", [(M.JOINT_PX, 0), (M.JOINT_PY, 1), (M.JOINT_PZ, 2)])
+def test_prismatic_joints_are_linear_columns_of_a_free_flyer_oracle(jtype, k):
+    _check_prismatic(_OracleBackend, jtype, k)
+
+
+@pytest.mark.gpu
+def test_spherical_joint_is_the_angular_half_of_a_free_flyer_gpu():
+    _check_spherical(_GpuBackend)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("jtype,k", [(M.JOINT_PX, 0), (M.JOINT_PY, 1), (M.JOINT_PZ, 2)])
+def test_prismatic_joints_are_linear_columns_of_a_free_flyer_gpu(jtype, k):
+    _check_prismatic(_GpuBackend, jtype, k)

@@ -99,6 +99,27 @@ def _check_prismatic(Backend, jtype, k):
     assert np.allclose(pr.aba(q, v, tau.reshape(1, 1)), 1.0, rtol=1e-10)
 
 
+def _one_joint_axis(jtype, axis):
+    m = M.Model("unaligned")
+    P = np.eye(4)
+    P[:3, 3] = (1.0, 0.0, 0.0)
+    j = m.addJoint(0, jtype, P, "unaligned", axis=axis)
+    m.appendBodyToJoint(j, M.Inertia(1.0, (0.5, 0.0, 0.0), np.eye(3)))
+    return m
+
+
+def _check_unaligned_vs_aligned(Backend, unaligned, aligned):
+    """unittest/joint-revolute.cpp:36-114 (vsRX) and joint-prismatic.cpp:236-316 (vsPX): the unaligned
+    joint about (1, 0, 0) against the aligned one: same model, q = v = a = 1."""
+    U, X = Backend(_one_joint_axis(unaligned, (1.0, 0.0, 0.0))), Backend(_one_joint(aligned, "aligned"))
+    q, v, a = _col(1.0), _col(1.0), _col(1.0)
+    tx, tu = X.rnea(q, v, a), U.rnea(q, v, a)
+    assert np.allclose(tu, tx, rtol=TOL, atol=1e-14)                                  # :80-85
+    assert np.allclose(U.aba(q, v, tu.reshape(1, 1)), X.aba(q, v, tx.reshape(1, 1)), rtol=1e-10)   # :87-92
+    assert np.allclose(U.M(q, v, a), X.M(q, v, a), rtol=TOL)                          # :94-98
+    assert np.allclose(U.J_local(q), X.J_local(q), rtol=TOL, atol=1e-14)              # :100-113
+
+
 def test_spherical_joint_is_the_angular_half_of_a_free_flyer_oracle():
     _check_spherical(_OracleBackend)
 
@@ -117,3 +138,17 @@ def test_spherical_joint_is_the_angular_half_of_a_free_flyer_gpu():
 @pytest.mark.parametrize("jtype,k", [(M.JOINT_PX, 0), (M.JOINT_PY, 1), (M.JOINT_PZ, 2)])
 def test_prismatic_joints_are_linear_columns_of_a_free_flyer_gpu(jtype, k):
     _check_prismatic(_GpuBackend, jtype, k)
+
+
+UNALIGNED = [(M.JOINT_REVOLUTE_UNALIGNED, M.JOINT_RX), (M.JOINT_PRISMATIC_UNALIGNED, M.JOINT_PX)]
+
+
+@pytest.mark.parametrize("unaligned,aligned", UNALIGNED)
+def test_unaligned_joint_about_x_equals_the_aligned_one_oracle(unaligned, aligned):
+    _check_unaligned_vs_aligned(_OracleBackend, unaligned, aligned)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("unaligned,aligned", UNALIGNED)
+def test_unaligned_joint_about_x_equals_the_aligned_one_gpu(unaligned, aligned):
+    _check_unaligned_vs_aligned(_GpuBackend, unaligned, aligned)

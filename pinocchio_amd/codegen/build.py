@@ -39,18 +39,23 @@ WANTS = {"rnea": [1, 33], "aba": [1, 33], "fkjac": [1, 2, 3], "deriv": [31, 15],
 # enough to transpose in one go).  Staging mode of the inputs: 0 = registers (the RNEA kernels use
 # ~150 of 512 VGPRs), 1 = the wave's global staging rows (ABA has no registers to spare).
 # (minv: BATCH_MAJOR only -- INSTANCE_MAJOR calls of the nv x nv outputs run on batch-major copies anyway)
-# fkjac: layout 2 for the Jacobian-only variant of models whose 6 * nv output rows fit the registers
-# that collect them (FKJAC_STAGED_ROWS)
+# fkjac: layout 2 for models whose outputs are emitted in increasing element order (fkjac.monotone):
+# both outputs are streamed out in chunks of 64 rows
 LAYOUTS = {"rnea": (0, 1, 2), "aba": (0, 1, 2), "fkjac": (0, 1, 2), "deriv": (0, 1), "minv": (1,), "prod": (1,)}
-FKJAC_STAGED_ROWS = 128
 STAGE_MODE = {"rnea": 0, "aba": 1, "fkjac": 0, "deriv": 0, "minv": 0, "prod": 0}
 STAGED_WANTS = [1]  # (the external-force variants read 6 * njoints more rows per lane anyway: not staged)
 
 
 def _layouts(algo: str, model) -> tuple:
-    if algo == "fkjac" and 6 * model.nv > FKJAC_STAGED_ROWS:
-        return (0, 1)
+    if algo == "fkjac":
+        from . import fkjac
+        if not fkjac.monotone(joints.ModelView(model)):
+            return (0, 1)
     return LAYOUTS[algo]
+
+
+def _staged_wants(algo: str):
+    return WANTS[algo] if algo == "fkjac" else STAGED_WANTS
 for _kv in os.environ.get("BRBD_CG_STAGE_MODE", "").split(","):  # experiment hook: "aba=0"
     if "=" in _kv:
         STAGE_MODE[_kv.split("=")[0]] = int(_kv.split("=")[1])
@@ -90,7 +95,9 @@ def _emit_algo(args):
     staged = 2 in layouts
     # rows of the staged matrices: q, v, third input, first output (fkjac: q in, the Jacobian out)
     rows = (nq, 0, 0, 6 * nv) if algo == "fkjac" else (nq, nv, nv, nv)
-    stage_pairs = (max(rows) + 1) // 2
+    rows2 = 12 * model.njoints if algo == "fkjac" else 0          # second output, when it is streamed too
+    stream = 1 if algo == "fkjac" else 0                          # outputs leave in chunks of 64 rows
+    stage_pairs = (max(rows[:3] + ((64,) if stream else rows[3:])) + 1) // 2
     stage_rows = (nq + 2 * nv) if (staged and STAGE_MODE[algo] == 1) else 0
     body = "%s_%s.inc" % (ident, algo)
     _write(os.path.join(out_dir, body), k.text)
@@ -106,6 +113,8 @@ def _emit_algo(args):
             "  // rows of q, v, the third input and the first output; staging of the layout-2 kernels",
             "  constexpr int SPEC_NQ = %d, SPEC_NV = %d, SPEC_NX = %d, SPEC_NO = %d, SPEC_STAGE_MODE = %d, SPEC_GLB = %d;" % (
                 rows + (STAGE_MODE[algo], k.glb)),
+            ] + (["  constexpr int SPEC_NO2 = %d, SPEC_OUT_STREAM = %d;  // (shadow the defaults of brbd_spec.hpp)" % (rows2, stream)]
+                 if stream else []) + [
             "  BRBD_SPEC_PROLOGUE(LAYOUT == 2 ? %d : %d)" % (max(k.lds // 2, stage_pairs), k.lds // 2),
             "  {  // one tile of 64 instances per workgroup: no loop, nothing for LICM to hoist",
             "    const int64_t tile = A.tile0 + blockIdx.x;",
@@ -119,7 +128,7 @@ def _emit_algo(args):
     import hashlib
     digest = hashlib.sha1((k.text + kern_text).encode()).hexdigest()[:16]
     for layout in layouts:
-        for w in (WANTS[algo] if layout != 2 else STAGED_WANTS):
+        for w in (WANTS[algo] if layout != 2 else _staged_wants(algo)):
             _write(os.path.join(out_dir, "spec_%s_%s_%d_%d.hip" % (ident, algo, layout, w)), "\n".join([
                 "// GENERATED by pinocchio_amd/codegen/build.py -- do not edit.",
                 "// body + template digest %s (this file changes, and is recompiled, exactly when they do)" % digest,
@@ -160,8 +169,7 @@ def emit_variant(out_dir: str, name: str, variant: str, pool=None) -> str:
             if layout not in layouts:
                 fn = ["nullptr"] * 4
             elif algo == "fkjac":   # variant index = WANT mask
-                fn = ["nullptr"] + [("%sk_fkjac<%d, %d>" % (ns, layout, w)) if (layout != 2 or w in STAGED_WANTS) else "nullptr"
-                                    for w in (1, 2, 3)]
+                fn = ["nullptr"] + ["%sk_fkjac<%d, %d>" % (ns, layout, w) for w in (1, 2, 3)]
             else:                 # variant index = position in WANTS
                 fn = [("%sk_%s<%d, %d>" % (ns, algo, layout, w)) if (layout != 2 or w in STAGED_WANTS) else "nullptr"
                       for w in WANTS[algo]]
@@ -217,7 +225,7 @@ def main(argv=None):
         stem = base[:-4]
         parts = stem.split("_")
         algo, layout, w = parts[-3], int(parts[-2]), int(parts[-1])
-        ok = algo in LAYOUTS and layout in LAYOUTS[algo] and w in (WANTS[algo] if layout != 2 else STAGED_WANTS)
+        ok = algo in LAYOUTS and layout in LAYOUTS[algo] and w in (WANTS[algo] if layout != 2 else _staged_wants(algo))
         if not ok:
             for ext in (".hip", ".o", ".usage"):
                 try:

@@ -4,6 +4,11 @@
 One forward sweep: liMi, oMi = oMparent * liMi, J[:, cols_i] = oMi.act(S_i) in the WORLD frame.
 Outputs: OUT = J (per instance 6 x nv column-major), OUT2 = oMi (per joint rotation column-major
 then translation; joint 0 = identity), the layout of include/brbd.h.
+
+Joints are visited in index order (parents come first) and every output is emitted in increasing
+element order: the INSTANCE_MAJOR kernels (layout 2) collect 64 rows at a time and write them out
+through LDS as soon as a chunk is complete (csrc/brbd_spec.hpp: SpecOutStream).  ``monotone(mv)``
+tells whether a model's dof numbering allows that (J rows follow idx_v).
 """
 from __future__ import annotations
 
@@ -12,10 +17,16 @@ from . import joints as J
 from .emit import ONE, ZERO, Emitter
 
 
+def monotone(mv: J.ModelView) -> bool:
+    return all(mv.parents[i] < i for i in range(1, mv.n)) and all(
+        mv.idx_v[i + 1] == mv.idx_v[i] + mv.nv(i) for i in range(1, mv.n - 1))
+
+
 def generate(mv: J.ModelView, e: Emitter) -> Emitter:
     kin = {}
     first = True
-    for i in J.forward_program(mv):
+    order = list(range(1, mv.n)) if monotone(mv) else J.forward_program(mv)
+    for i in order:
         p = mv.parents[i]
         e.begin_visit("FK %d" % i)
         if first:
@@ -31,8 +42,8 @@ def generate(mv: J.ModelView, e: Emitter) -> Emitter:
             R, t = A.rot_mul(e, Rp, Rl), A.rot_vec(e, Rp, tl, tp)
         if mv.children[i]:
             kin[i] = e.park([x for row in R for x in row] + list(t), "stack")
-        for r in range(3):
-            for c in range(3):
+        for c in range(3):
+            for r in range(3):
                 e.out(12 * i + 3 * c + r, R[r][c], which=2)
         for k in range(3):
             e.out(12 * i + 9 + k, t[k], which=2)

@@ -360,9 +360,9 @@ int launch_algo(brbd_model* m, int algo, KArgs& A, int layout, hipStream_t strea
     if (sk && layout == BRBD_INSTANCE_MAJOR && !no_staged && (algo == BRBD_ALGO_RNEA || algo == BRBD_ALGO_ABA) &&
         sk->fn[2][variant] && A.ldq == F.nq && A.ldv == F.nv && A.lda == F.nv && A.ldout == F.nv)
       klayout = 2;
-    // (forward kinematics + Jacobians: q staged in, the 6 nv rows of J collected and transposed out)
+    // (forward kinematics + Jacobians: q staged in, J and oMi streamed out in chunks of 64 rows)
     if (sk && layout == BRBD_INSTANCE_MAJOR && !no_staged && algo == BRBD_ALGO_FK_JAC && sk->fn[2][variant] &&
-        A.ldq == F.nq && A.ldout == 6 * (int64_t)F.nv)
+        A.ldq == F.nq && (!A.out || A.ldout == 6 * (int64_t)F.nv) && (!A.out2 || A.ldout2 == 12 * (int64_t)F.njoints))
       klayout = 2;
     if (sk && !sk->fn[klayout][variant]) sk = nullptr;
   }

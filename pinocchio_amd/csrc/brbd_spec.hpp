@@ -249,6 +249,55 @@ struct SpecOut<2, AUX, N> {  // collected in registers, transposed through LDS a
   }
 };
 
+// Outputs whose rows arrive in increasing order (FK + Jacobians, codegen/fkjac.py): CH rows are
+// collected in registers and leave through LDS as soon as the chunk is complete -- element
+// (row, instance) of the chunk goes to LDS as [instance][row], and 64 consecutive elements of that
+// flat order are one store: runs of CH * 8 bytes per instance.  `d` is a literal at every call
+// site, so the chunk bookkeeping folds away.
+template <int LAYOUT, int AUX, int N, int STREAM>
+struct SpecOutSel : SpecOut<LAYOUT, AUX, N> {
+  DI SpecOutSel(double* base, unsigned bytes, unsigned ld8, int64_t b, unsigned long long* oob_, const SpecStage&)
+      : SpecOut<LAYOUT, AUX, N>(base, bytes, ld8, b, oob_) {}
+};
+template <int AUX, int N>
+struct SpecOutSel<2, AUX, N, 1> {
+  static constexpr int CH = 64;
+  mutable double r[CH];
+  __amdgpu_buffer_rsrc_t rs;
+  unsigned t0, nbytes;
+  int lane;
+  double* lds;
+  unsigned long long* oob;
+  DI SpecOutSel(double* base, unsigned bytes, unsigned, int64_t, unsigned long long* oob_, const SpecStage& sc)
+      : rs(spec_rsrc(base, bytes)), t0((unsigned)sc.tile * (unsigned)(WAVE * N * 8)), nbytes(bytes), lane(sc.lane),
+        lds(sc.lds), oob(oob_) {}
+  DI void flush_chunk(int c0, int nr) const {  // (c0, nr: literals once put() is inlined)
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < CH; ++k)
+      if (k < nr) lds[lane * nr + k] = r[k];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < CH; ++j)
+      if (j < nr) {
+        const unsigned f = (unsigned)(j * WAVE + lane), inst = f / (unsigned)nr, row = f % (unsigned)nr;
+        const unsigned off = t0 + inst * (unsigned)(N * 8) + (unsigned)(c0 * 8) + row * 8u;
+        SPEC_CHECK(oob, off < nbytes ? off : 0u, 8u, nbytes, 9);
+        if (off + 8u <= nbytes)  // (instances past the end of the batch)
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, lds[f]), rs, off, 0, AUX);
+      }
+  }
+  DI void put(int d, unsigned, double x) const {
+    r[d % CH] = x;
+    const int c0 = d - d % CH;                  // first row of d's chunk
+    const int nr = N - c0 < CH ? N - c0 : CH;   // rows of that chunk
+    if (d == c0 + nr - 1) flush_chunk(c0, nr);  // rows arrive in increasing order: the chunk is complete
+  }
+  DI void flush(double*, unsigned, const SpecStage&) const {}
+};
+// defaults for the kernel templates that do not stream their outputs (shadowed in codegen/fkjac's)
+constexpr int SPEC_NO2 = 0, SPEC_OUT_STREAM = 0;
+
 // sin and cos of a joint angle in ~45 straight-line instructions: 3-term Cody-Waite reduction by
 // pi/2 carried by FMAs (exact products), fdlibm's minimax kernels on [-pi/4, pi/4] (k_sin.c /
 // k_cos.c coefficients), quadrant fix-up.  Max abs error 2.3e-16 against glibc
@@ -373,8 +422,8 @@ DI void spec_sincos(double x, double& so, double& co) {
   SpecIn<LAYOUT, SPEC_IN_AUX, SPEC_NX, SPEC_STAGE_MODE> mx(A.a, A.nb[2], ldx8, inst, A.oob, sc, SPEC_NQ + SPEC_NV); \
   mq.commit(sc); mv.commit(sc); mx.commit(sc); /* layout 2: all loads were issued above */           \
   if ((LAYOUT) == 2) __syncthreads();                                                                \
-  const SpecOut<LAYOUT, SPEC_OUT_AUX, SPEC_NO> mo(A.out, A.nb[3], ldo8, inst, A.oob);                \
-  const SpecMat<LAY_, SPEC_OUT_AUX> mo2(A.out2, A.nb[4], ldo28, inst, A.oob);                        \
+  const SpecOutSel<LAYOUT, SPEC_OUT_AUX, SPEC_NO, SPEC_OUT_STREAM> mo(A.out, A.nb[3], ldo8, inst, A.oob, sc);      \
+  const SpecOutSel<(SPEC_OUT_STREAM ? (LAYOUT) : LAY_), SPEC_OUT_AUX, SPEC_NO2, SPEC_OUT_STREAM> mo2(A.out2, A.nb[4], ldo28, inst, A.oob, sc); \
   const SpecMat<LAY_, SPEC_OUT_AUX> mo3(A.out3, A.nb[5], ldo38, inst, A.oob);                        \
   const SpecMat<LAY_, SPEC_OUT_AUX> mo4(A.out4, A.nb[6], ldo48, inst, A.oob);                        \
   const SpecMat<LAY_, SPEC_IN_AUX> mf(A.fext, A.nb[7], ldf8, inst, A.oob);                           \

@@ -171,4 +171,14 @@ if "layouts" in which:   # the reference's own layout, device resident, against 
     tb = timed(dm, capi.ALGO_FK_JAC, lambda: parallel.computeJointJacobians(pool, q), 10)
     ti = timed(dm, capi.ALGO_FK_JAC, lambda: parallel.computeJointJacobians(pool, qi), 10)
     print(json.dumps({"config": "arm7 FK+J (J only) B=1048576 by layout", "batch_major_us": tb * 1e6, "instance_major_us": ti * 1e6}))
+    tb2 = timed(dm, capi.ALGO_FK_JAC, lambda: parallel.computeJointJacobians(pool, q, want_oMi=True), 10)
+    ti2 = timed(dm, capi.ALGO_FK_JAC, lambda: parallel.computeJointJacobians(pool, qi, want_oMi=True), 10)
+    print(json.dumps({"config": "arm7 FK+J (J + oMi) B=1048576 by layout", "batch_major_us": tb2 * 1e6, "instance_major_us": ti2 * 1e6}))
+    pool.release()
+    m = S.simple_humanoid(); B = 1 << 18; pool = parallel.ModelPool(m, 1); dm = pool.device_model(0)
+    q, _, _ = inputs(m, B)
+    qi = q.t().contiguous().t()
+    tb2 = timed(dm, capi.ALGO_FK_JAC, lambda: parallel.computeJointJacobians(pool, q, want_oMi=True), 5)
+    ti2 = timed(dm, capi.ALGO_FK_JAC, lambda: parallel.computeJointJacobians(pool, qi, want_oMi=True), 5)
+    print(json.dumps({"config": "simple_humanoid FK+J (J + oMi) B=262144 by layout", "batch_major_us": tb2 * 1e6, "instance_major_us": ti2 * 1e6}))
     pool.release()

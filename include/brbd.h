@@ -304,7 +304,11 @@ int64_t brbd_debug_oob_count(brbd_model* m);
  * device time in milliseconds, and forgets them.  enabled = 2 ("chained"): the event that closes
  * one launch also opens the next launch of the same handle on the same stream, i.e. one event
  * per launch instead of two (an event costs the stream about 3 us); a launch's time then includes
- * the gap to its predecessor, and whatever else the caller put on the stream in between. */
+ * the gap to its predecessor, and whatever else the caller put on the stream in between.
+ * enabled = 3: a call that is ONE dispatch of a model-compiled kernel carries its own begin / end
+ * timestamps (hipExtLaunchKernelGGL): the time is the kernel's alone, as a profiler reports it, but
+ * the stream pays more per launch than with chained events (MI355X: +7 us per RNEA + ABA step
+ * against +4.5); every other launch is timed as with 2. */
 int brbd_set_timing(brbd_model* m, int enabled);
 int brbd_kernel_time(brbd_model* m, int algo, int32_t* launches, double* total_ms);
 

@@ -6,6 +6,7 @@
 // There is NO CPU fallback in this library: without a HIP device every compute entry point
 // fails with BRBD_ERR_NO_DEVICE / BRBD_ERR_RUNTIME.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <dlfcn.h>
 
 #include <cstdio>
@@ -274,7 +275,7 @@ struct Timer {
     if (!m->timing || algo < 0) return BRBD_OK;
     // chained timing (brbd_set_timing(m, 2)): the event that closed the previous launch of this
     // handle on this stream opens this one: one event per launch instead of two
-    if (m->timing == 2 && m->last_stop && m->last_stream == s) {
+    if (m->timing >= 2 && m->last_stop && m->last_stream == s) {
       t.start = m->last_stop;
     } else {
       t.start = std::make_shared<Ev>();
@@ -431,7 +432,10 @@ int launch_algo(brbd_model* m, int algo, KArgs& A, int layout, hipStream_t strea
     A.ws = ctx->d_ws;
   }
   A.ws_bytes = (uint32_t)((size_t)grid * A.ws_stride * 8);
-  Timer tm{m, fixed ? -1 : algo, stream};
+  // timing mode 3 applies to calls that are ONE dispatch of a compiled kernel; anything else is timed
+  // between chained events like mode 2
+  const bool dispatch_timed = m->timing == 3 && stat && !fixed && A.ntiles <= grid;
+  Timer tm{m, (fixed || dispatch_timed) ? -1 : algo, stream};
   if ((rc = tm.begin())) return rc;
   const dim3 g((unsigned)grid), b(WAVE);
   if (stat) {
@@ -443,6 +447,19 @@ int launch_algo(brbd_model* m, int algo, KArgs& A, int layout, hipStream_t strea
       (void)hipMemset(d_trace, 0, 4096 * sizeof(long long));
       A.prog3 = reinterpret_cast<const Op*>(d_trace);
     }
+    if (dispatch_timed) {
+      // brbd_set_timing(m, 3): the one dispatch of this call carries its own begin / end timestamps
+      // (hipExtLaunchKernelGGL): no marker packets between the launches of a stream
+      TimedLaunch t{};
+      t.start = std::make_shared<Ev>();
+      t.stop = std::make_shared<Ev>();
+      HIP_TRY(hipEventCreate(&t.start->e));
+      HIP_TRY(hipEventCreate(&t.stop->e));
+      A.tile0 = 0;
+      hipExtLaunchKernelGGL(sfn, dim3((unsigned)A.ntiles), b, 0, stream, t.start->e, t.stop->e, 0, A);
+      std::lock_guard<std::mutex> g(m->mu);
+      m->timed[algo].push_back(t);
+    } else
     for (int64_t t0 = 0; t0 < A.ntiles; t0 += grid) {
       A.tile0 = t0;
       const int64_t n = A.ntiles - t0 < grid ? A.ntiles - t0 : grid;
@@ -1700,7 +1717,7 @@ int brbd_model_outputs_prezeroed(brbd_model* m, int enabled) {
 
 int brbd_set_timing(brbd_model* m, int enabled) {
   if (!m) return fail(BRBD_ERR_INVALID_ARGUMENT, "model handle is NULL");
-  m->timing = enabled == 2 ? 2 : (enabled != 0 ? 1 : 0);
+  m->timing = (enabled == 2 || enabled == 3) ? enabled : (enabled != 0 ? 1 : 0);
   {
     std::lock_guard<std::mutex> g(m->mu);
     m->last_stop.reset();

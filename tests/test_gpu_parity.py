@@ -555,3 +555,30 @@ def test_compiled_kernels_large_angles():
     tau = parallel.rneaInParallel(1, pool, q, v, a)
     assert rel_err_cols(tau, O.rnea(q, v, a)).max() < TOL_RNEA
     pool.release()
+
+
+def test_dispatch_timestamps_timing_mode(torch_mod):
+    """brbd_set_timing(m, 3): single-dispatch calls of the compiled kernels are timed by their own
+    begin / end timestamps: as many records as launches, each shorter than the chained-event time."""
+    torch = torch_mod
+    model = S.simple_humanoid()
+    pool = parallel.ModelPool(model, 1)
+    dm = pool.device_model(0)
+    q, v, a = (torch.from_numpy(np.ascontiguousarray(x)).to("cuda:0") for x in inputs(model, 4096, 3))
+    times = {}
+    for mode in (2, 3):
+        for _ in range(5):
+            parallel.rneaInParallel(1, pool, q, v, a)
+        torch.cuda.synchronize()
+        dm.kernel_time(capi.ALGO_RNEA)
+        capi.check(capi.lib().brbd_set_timing(dm.handle, mode))
+        for _ in range(20):
+            tau = parallel.rneaInParallel(1, pool, q, v, a)
+        torch.cuda.synchronize()
+        capi.check(capi.lib().brbd_set_timing(dm.handle, 0))
+        n, ms = dm.kernel_time(capi.ALGO_RNEA)
+        assert n == 20 and ms > 0
+        times[mode] = ms / n
+    assert times[3] <= times[2]
+    assert rel_err_cols(tau.cpu().numpy(), oracle.Oracle(model).rnea(*inputs(model, 4096, 3))).max() < TOL_RNEA
+    pool.release()

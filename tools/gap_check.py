@@ -16,14 +16,15 @@ t0 = time.perf_counter()
 while time.perf_counter() - t0 < 0.5: step()
 torch.cuda.synchronize()
 res = {}
-for mode in (0, 2, 0, 2):
+for mode in (0, 2, 3, 0, 2, 3):
     dm.kernel_time(capi.ALGO_RNEA); dm.kernel_time(capi.ALGO_ABA)
     capi.check(capi.lib().brbd_set_timing(dm.handle, mode))
     for _ in range(300): step()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(2000): step()
     torch.cuda.synchronize(); t = (time.perf_counter() - t0) / 2000
-    res.setdefault("timing_%d_us" % mode, []).append(round(t * 1e6, 2))
+    n_r, ms_r = dm.kernel_time(capi.ALGO_RNEA); n_a, ms_a = dm.kernel_time(capi.ALGO_ABA)
+    res.setdefault("timing_%d_us" % mode, []).append((round(t * 1e6, 2), round(ms_r / max(n_r, 1) * 1e3, 2), round(ms_a / max(n_a, 1) * 1e3, 2)))
     capi.check(capi.lib().brbd_set_timing(dm.handle, 0))
     dm.kernel_time(capi.ALGO_RNEA); dm.kernel_time(capi.ALGO_ABA)
 print(json.dumps(res))

@@ -298,20 +298,25 @@ struct SpecOutSel<2, AUX, N, 1> {
 // defaults for the kernel templates that do not stream their outputs (shadowed in codegen/fkjac's)
 constexpr int SPEC_NO2 = 0, SPEC_OUT_STREAM = 0;
 
-// sin and cos of a joint angle in ~45 straight-line instructions: 3-term Cody-Waite reduction by
-// pi/2 carried by FMAs (exact products), fdlibm's minimax kernels on [-pi/4, pi/4] (k_sin.c /
-// k_cos.c coefficients), quadrant fix-up.  Max abs error 2.3e-16 against glibc
-// (tools/ubench/sincos_check.c).  Deliberately BRANCH-FREE: the compiled kernels stream through
-// their code once, so every taken branch (e.g. around an inlined large-argument path) lands on an
-// instruction-cache miss -- measured at ~1000 cycles per joint, more than the joint's arithmetic.
+// sin and cos of a joint angle in ~35 straight-line instructions: 2-term Cody-Waite reduction by
+// pi/2 carried by FMAs (exact products; the third term, 1.5e-33 n, is below 1e-17 for the whole
+// domain), fdlibm's minimax kernels on [-pi/4, pi/4] (k_sin.c / k_cos.c coefficients), quadrant
+// fix-up on the integer bits.  n = rint(x 2/pi) comes from one FMA with 1.5 * 2^52: the sum's ulp
+// is 1, so the FMA rounds x 2/pi to the nearest integer in one rounding and leaves n mod 2^32 (two's
+// complement) in the low mantissa word -- no rint, no float -> int conversion.  Max abs error
+// 2.3e-16 against glibc for |x| <= 1e12, 4.5e-16 at 1e15 (tools/ubench/sincos_check.c).
+// Deliberately BRANCH-FREE: the compiled kernels stream through their code once, so every taken
+// branch (e.g. around an inlined large-argument path) lands on an instruction-cache miss --
+// measured at ~1000 cycles per joint, more than the joint's arithmetic.
 // Valid for |x| < 2^50 rad; beyond that (and for inf / nan) the result is NaN, where the reference
 // (math/sincos.hpp:47-61 -> glibc) returns the sine of the rounded double.  Models whose inputs can
 // be that large run on the table-driven kernels (brbd_model_use_compiled(m, 0)).
 DI void spec_sincos(double x, double& so, double& co) {
-  const double n = __builtin_rint(x * 0.63661977236758138);
+  const double t = __builtin_fma(x, 0.63661977236758138, 6755399441055744.0);
+  const double n = t - 6755399441055744.0;
+  const unsigned q = (unsigned)__double2loint(t);  // n mod 2^32
   double r = __builtin_fma(-n, 1.5707963267948966, x);
   r = __builtin_fma(-n, 6.123233995736766e-17, r);
-  r = __builtin_fma(-n, -1.4973849048591698e-33, r);
   r = (__builtin_fabs(x) < 1125899906842624.0) ? r : __builtin_nan("");
   const double z = r * r;
   double ps = __builtin_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
@@ -326,10 +331,11 @@ DI void spec_sincos(double x, double& so, double& co) {
   pc = __builtin_fma(z, pc, -1.38888888888741095749e-03);
   pc = __builtin_fma(z, pc, 4.16666666666666019037e-02);
   pc = __builtin_fma(z * z, pc, __builtin_fma(z, -0.5, 1.0));
-  const int q = (int)__builtin_fma(-4.0, __builtin_rint(n * 0.25), n);  // n mod 4 in [-2, 2]
-  const double s = (q & 1) ? pc : ps, c = (q & 1) ? ps : pc;
-  so = (q & 2) ? -s : s;
-  co = ((q + 1) & 2) ? -c : c;
+  const bool odd = q & 1u;
+  const double s = odd ? pc : ps, c = odd ? ps : pc;
+  // sin changes sign in quadrants 2, 3 (bit 1 of q), cos in 1, 2 (bit 1 of q + 1): xor into the sign bit
+  so = __hiloint2double(__double2hiint(s) ^ (int)((q << 30) & 0x80000000u), __double2loint(s));
+  co = __hiloint2double(__double2hiint(c) ^ (int)(((q + 1u) << 30) & 0x80000000u), __double2loint(c));
 }
 
 // ---- the macros the generated bodies use (codegen/emit.py: MACROS) ----

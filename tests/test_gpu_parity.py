@@ -533,7 +533,7 @@ def test_compiled_kernels_armature_and_gravity_change_selection():
 
 
 def test_compiled_kernels_large_angles():
-    """spec_sincos is branch-free: max abs error against glibc 2.2e-16 for |q| <= 1e12 and 1e-14 at
+    """spec_sincos is branch-free: max abs error against glibc 2.2e-16 for |q| <= 1e12 and 4.5e-16 at
     1e15 (tools/ubench/sincos_check.c), so the results keep the standard tolerances at any angle a
     caller can mean; for |q| >= 2^50 rad (1.1e15) it returns NaN by design, while the
     table-driven kernels follow the library path like the reference."""

@@ -310,6 +310,13 @@ int64_t brbd_debug_oob_count(brbd_model* m);
  * the stream pays more per launch than with chained events (MI355X: +7 us per RNEA + ABA step
  * against +4.5); every other launch is timed as with 2. */
 int brbd_set_timing(brbd_model* m, int enabled);
+/* Time only every period-th launch of each algorithm (default 1: all of them), counted per handle
+ * from this call on: a long run then pays for the events of a sample of its launches only (MI355X,
+ * RNEA + ABA step: 3.2 us per step with chained events on every launch).  With enabled = 2 the
+ * timed launches of different algorithms still share events when they follow each other directly
+ * (launch k of RNEA and launch k of ABA are timed together); an untimed launch in between breaks
+ * the chain, so a timed launch never includes an untimed one.  No reference counterpart. */
+int brbd_set_timing_period(brbd_model* m, int period);
 int brbd_kernel_time(brbd_model* m, int algo, int32_t* launches, double* total_ms);
 
 #ifdef __cplusplus

@@ -36,7 +36,7 @@ SYMBOLS = (
     "brbd_model_create", "brbd_model_destroy", "brbd_model_dims", "brbd_workspace_bytes",
     "brbd_rnea", "brbd_aba", "brbd_rnea_fext", "brbd_aba_fext", "brbd_fk_jacobians", "brbd_joint_jacobian", "brbd_rnea_derivatives",
     "brbd_transpose_to_batch_major", "brbd_transpose_to_instance_major",
-    "brbd_set_timing", "brbd_kernel_time", "brbd_model_compiled_kernels", "brbd_model_use_compiled", "brbd_model_outputs_prezeroed", "brbd_model_canonical_form",
+    "brbd_set_timing", "brbd_set_timing_period", "brbd_kernel_time", "brbd_model_compiled_kernels", "brbd_model_use_compiled", "brbd_model_outputs_prezeroed", "brbd_model_canonical_form",
     "brbd_load_compiled_kernels", "brbd_integrate", "brbd_minverse", "brbd_aba_derivatives",
     "brbd_aba_noalloc", "brbd_host_register", "brbd_host_unregister", "brbd_debug_oob_count",
 )
@@ -164,6 +164,8 @@ def lib():
     L.brbd_model_outputs_prezeroed.argtypes = [vp, ci]
     L.brbd_set_timing.restype = ci
     L.brbd_set_timing.argtypes = [vp, ci]
+    L.brbd_set_timing_period.restype = ci
+    L.brbd_set_timing_period.argtypes = [vp, ci]
     L.brbd_kernel_time.restype = ci
     L.brbd_kernel_time.argtypes = [vp, ci, ctypes.POINTER(i32), dp]
     _lib = L
@@ -233,10 +235,13 @@ class DeviceModel:
         """Derivative outputs under the reference's contract (caller zeroed them): see include/brbd.h"""
         check(lib().brbd_model_outputs_prezeroed(self.handle, 1 if on else 0))
 
-    def set_timing(self, on: bool, chained: bool = False):
+    def set_timing(self, on: bool, chained: bool = False, dispatch: bool = False, period: int = 1):
         """hipEvents around every kernel launch; ``chained``: one shared event between consecutive
-        launches instead of two (include/brbd.h: brbd_set_timing)."""
-        check(lib().brbd_set_timing(self.handle, (2 if chained else 1) if on else 0))
+        launches instead of two; ``dispatch``: the compiled kernels' dispatches carry their own begin /
+        end timestamps; ``period``: only every period-th launch of an algorithm is timed
+        (include/brbd.h: brbd_set_timing, brbd_set_timing_period)."""
+        check(lib().brbd_set_timing(self.handle, (3 if dispatch else 2 if chained else 1) if on else 0))
+        check(lib().brbd_set_timing_period(self.handle, max(int(period), 1) if on else 1))
 
     def kernel_time(self, algo: int):
         n = ctypes.c_int32(0)

@@ -110,6 +110,8 @@ struct brbd_model {
   bool use_lds = true;
   bool warned_4g = false;
   int timing = 0;  // 0 off, 1 two events per launch, 2 chained (one event per launch)
+  int timing_period = 1;            // brbd_set_timing_period: every period-th launch of an algorithm is timed
+  uint64_t timing_count[6] = {0, 0, 0, 0, 0, 0};
   std::shared_ptr<Ev> last_stop;
   hipStream_t last_stream = nullptr;
   std::vector<TimedLaunch> timed[6];
@@ -265,6 +267,17 @@ void fill_common(const brbd_model* m, KArgs& A, int64_t B) {
   A.oob = m->d_oob;
 }
 
+// brbd_set_timing_period: is this launch of `algo` one of the timed ones?  An untimed launch breaks
+// the chain of mode 2 (the next timed launch opens with an event of its own).
+static bool timing_sampled(brbd_model* m, int algo) {
+  if (!m->timing || algo < 0) return false;
+  if (m->timing_period <= 1) return true;
+  std::lock_guard<std::mutex> g(m->mu);
+  const bool yes = m->timing_count[algo]++ % (uint64_t)m->timing_period == 0;
+  if (!yes) m->last_stop.reset();
+  return yes;
+}
+
 struct Timer {
   brbd_model* m;
   int algo;
@@ -272,7 +285,7 @@ struct Timer {
   TimedLaunch t{};
   bool on = false;
   int begin() {
-    if (!m->timing || algo < 0) return BRBD_OK;
+    if (!timing_sampled(m, algo)) return BRBD_OK;
     // chained timing (brbd_set_timing(m, 2)): the event that closed the previous launch of this
     // handle on this stream opens this one: one event per launch instead of two
     if (m->timing >= 2 && m->last_stop && m->last_stream == s) {
@@ -434,8 +447,9 @@ int launch_algo(brbd_model* m, int algo, KArgs& A, int layout, hipStream_t strea
   A.ws_bytes = (uint32_t)((size_t)grid * A.ws_stride * 8);
   // timing mode 3 applies to calls that are ONE dispatch of a compiled kernel; anything else is timed
   // between chained events like mode 2
-  const bool dispatch_timed = m->timing == 3 && stat && !fixed && A.ntiles <= grid;
-  Timer tm{m, (fixed || dispatch_timed) ? -1 : algo, stream};
+  const bool dispatch_mode = m->timing == 3 && stat && !fixed && A.ntiles <= grid;
+  const bool dispatch_timed = dispatch_mode && timing_sampled(m, algo);
+  Timer tm{m, (fixed || dispatch_mode) ? -1 : algo, stream};
   if ((rc = tm.begin())) return rc;
   const dim3 g((unsigned)grid), b(WAVE);
   if (stat) {
@@ -1722,6 +1736,15 @@ int brbd_set_timing(brbd_model* m, int enabled) {
     std::lock_guard<std::mutex> g(m->mu);
     m->last_stop.reset();
   }
+  return BRBD_OK;
+}
+
+int brbd_set_timing_period(brbd_model* m, int period) {
+  if (!m || period < 1) return fail(BRBD_ERR_INVALID_ARGUMENT, "model handle is NULL or period < 1");
+  std::lock_guard<std::mutex> g(m->mu);
+  m->timing_period = period;
+  for (auto& c : m->timing_count) c = 0;
+  m->last_stop.reset();
   return BRBD_OK;
 }
 

@@ -582,3 +582,37 @@ def test_dispatch_timestamps_timing_mode(torch_mod):
     assert times[3] <= times[2]
     assert rel_err_cols(tau.cpu().numpy(), oracle.Oracle(model).rnea(*inputs(model, 4096, 3))).max() < TOL_RNEA
     pool.release()
+
+
+def test_timing_period_samples_launches(torch_mod):
+    """brbd_set_timing_period(m, p): every p-th launch of each algorithm is timed, in every timing
+    mode; a timed launch never spans an untimed one (its time stays that of ONE launch); period 1
+    restores timing of every launch."""
+    torch = torch_mod
+    model = S.simple_humanoid()
+    pool = parallel.ModelPool(model, 1)
+    dm = pool.device_model(0)
+    q, v, a = (torch.from_numpy(np.ascontiguousarray(x)).to("cuda:0") for x in inputs(model, 4096, 3))
+    tau = parallel.rneaInParallel(1, pool, q, v, a)
+    for _ in range(5):
+        parallel.abaInParallel(1, pool, q, v, tau)
+    torch.cuda.synchronize()
+    per_launch = {}
+    for mode, period, expect in ((2, 1, 24), (2, 8, 3), (3, 8, 3), (1, 5, 5), (3, 1, 24)):
+        dm.kernel_time(capi.ALGO_RNEA), dm.kernel_time(capi.ALGO_ABA)
+        dm.set_timing(True, chained=mode == 2, dispatch=mode == 3, period=period)
+        for _ in range(24):
+            parallel.rneaInParallel(1, pool, q, v, a, tau)
+            ddq = parallel.abaInParallel(1, pool, q, v, tau)
+        torch.cuda.synchronize()
+        dm.set_timing(False)
+        (n_r, ms_r), (n_a, ms_a) = dm.kernel_time(capi.ALGO_RNEA), dm.kernel_time(capi.ALGO_ABA)
+        assert n_r == expect and n_a == expect, (mode, period, n_r, n_a)
+        per_launch[(mode, period)] = (ms_r / n_r, ms_a / n_a)
+    # a sampled launch's time is one launch's, not the 8 steps since the previous sample
+    for key in ((2, 8), (3, 8)):
+        assert per_launch[key][0] < 3 * per_launch[(2, 1)][0] and per_launch[key][1] < 3 * per_launch[(2, 1)][1]
+    with pytest.raises(capi.BrbdInvalidArgument):
+        capi.check(capi.lib().brbd_set_timing_period(dm.handle, 0))
+    assert rel_err_cols(ddq.cpu().numpy(), a.cpu().numpy()).max() < TOL_ABA
+    pool.release()

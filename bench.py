@@ -174,10 +174,12 @@ def main():
     # hipEvents on the launch stream: the dispatches of the model-compiled kernels carry their own
     # begin / end timestamps (brbd_set_timing(m, 3); the table-driven kernels are timed between
     # chained events), for one launch in `period` of each kernel: events on every launch cost the
-    # stream 3 us per step (tools/gap_check.py), which is the harness's time, not the path's.  At
-    # least 64 launches of each kernel are timed whenever the run has that many steps.
-    period = max(1, min(16, args.steps // 64))
-    dm.set_timing(True, dispatch=True, period=period)
+    # stream 3 us per step (tools/gap_check.py), which is the harness's time, not the path's.
+    # Period 16 for long runs (125 timed launches of each kernel in the default 2000 steps), at least
+    # 8 timed launches in short ones; runs too short to sample time every launch between chained
+    # events (the cheaper way to time ALL launches).
+    period = max(1, min(16, args.steps // 8))
+    dm.set_timing(True, chained=period == 1, dispatch=period > 1, period=period)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -317,8 +319,9 @@ def main():
                 "batch_per_gpu": B,
                 "evals_per_step_per_gpu": evals_per_step,
                 "rnea_kernel_ms": avg_r if do_rnea else None, "aba_kernel_ms": avg_a if do_aba else None,
-                "kernel_timing": {"how": "begin / end timestamps of the dispatch (hipExtLaunchKernelGGL events on the "
-                                         "launch stream), one launch in `period` inside the timed region",
+                "kernel_timing": {"how": ("begin / end timestamps of the dispatch (hipExtLaunchKernelGGL events on the "
+                                          "launch stream), one launch in `period` inside the timed region") if period > 1
+                                  else "chained hipEvents on the launch stream, every launch",
                                   "period": period, "timed_launches": {"rnea": n_r, "aba": n_a}},
                 "rnea_evals_per_s_kernel": B / (avg_r * 1e-3) if avg_r > 0 else None,
                 "aba_evals_per_s_kernel": B / (avg_a * 1e-3) if avg_a > 0 else None,

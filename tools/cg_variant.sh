@@ -13,6 +13,18 @@ sed -i 's#"../brbd_spec.hpp"#"brbd_spec.hpp"#' $D/gen/spec_*.hip
 # KATTR: extra kernel attribute, e.g. KATTR='__attribute__((amdgpu_waves_per_eu(2,2)))'
 # NOBAR="rnea aba": drop the scheduling barriers between the visits of these algorithms' bodies
 for alg in $NOBAR; do sed -i 's/^VISIT_END();$//' $D/gen/*_$alg.inc; done
+# DEFER_OUT="aba": move the first output's stores of these bodies to the end of the body (experiment:
+# do stores interleaved with pass 3's loads stall the in-order vmcnt waits?)
+for alg in $DEFER_OUT; do for f in $D/gen/*_$alg.inc; do python3 - "$f" <<'PY'
+import sys
+p = sys.argv[1]; L = open(p).read().split("\n")
+outs = [x for x in L if x.startswith("OUT(")]
+rest = [x for x in L if not x.startswith("OUT(")]
+while rest and rest[-1] == "": rest.pop()
+assert rest[-1] == "VISIT_END();"
+open(p, "w").write("\n".join(rest[:-1] + outs + ["VISIT_END();", ""]))
+PY
+done; done
 if [ -n "$KATTR" ]; then sed -i "s/__launch_bounds__(WAVE)/__launch_bounds__(WAVE) $KATTR/" $D/gen/*.kern.inc; fi
 sed -e 's#"gen/registry.inc"#"'$D'/gen/registry.inc"#' -e 's#"../../include/brbd.h"#"brbd.h"#' pinocchio_amd/csrc/brbd_capi.hip > $D/gen/spec_capi.hip
 ls $D/gen/spec_*.hip | xargs -P 8 -I{} sh -c "/opt/rocm/bin/hipcc $FLAGS -I include -I $D/gen -c -o {}.o {} -Rpass-analysis=kernel-resource-usage 2> {}.usage || { grep error {}.usage; exit 255; }"

@@ -43,6 +43,8 @@ def parse():
     p.add_argument("--algo", default="rnea+aba", choices=["rnea+aba", "rnea", "aba"])
     p.add_argument("--plugin", action="append", default=[],
                    help="kernel plugin(s) built by `python -m pinocchio_amd.codegen.plugin` for this model")
+    p.add_argument("--repeats", type=int, default=9,
+                   help="the --steps long timed region is run this many times; the line reports the median")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
     return p.parse_args()
@@ -169,27 +171,38 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    # The timed region holds nothing but the calls (like the loop of benchmark/timings-parallel.cpp:101-112):
+    # kernel timing is OFF in it.  `steps` steps between two fences, MAX over ranks; a region of 20
+    # steps lasts 1 ms, so it is repeated `repeats` times and the line carries the median region.
+    dm.set_timing(False)
+    regions = []
+    for _ in range(max(args.repeats, 1)):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        regions.append(time.perf_counter() - t0)
+    if dist is not None:
+        t = torch.tensor(regions, dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        regions = [float(x) for x in t.tolist()]
+    elapsed = float(np.median(regions))
+    # Kernel durations for the roofline, in a region of their own AFTER the timed one: the same step
+    # 1024 more times, ONE launch in 16 of each kernel carrying its own begin / end timestamps
+    # (brbd_set_timing(m, 3), hipExtLaunchKernelGGL; the table-driven kernels between chained hipEvents
+    # on the launch stream).  Timing events on every launch cost the stream 5-19 us per step and
+    # lengthen the timed dispatches themselves (44.7 instead of 38 us for ABA), sampled ones 0.8 us
+    # per step (tools/gap_check.py) -- either way they are the harness's time, not the path's, which
+    # is why the timed region has none.
+    k_timed, period = 1024, 16
     dm.kernel_time(capi.ALGO_RNEA)
     dm.kernel_time(capi.ALGO_ABA)
-    # hipEvents on the launch stream: the dispatches of the model-compiled kernels carry their own
-    # begin / end timestamps (brbd_set_timing(m, 3); the table-driven kernels are timed between
-    # chained events), for one launch in `period` of each kernel: events on every launch cost the
-    # stream 3 us per step (tools/gap_check.py), which is the harness's time, not the path's.
-    # Period 16 for long runs (125 timed launches of each kernel in the default 2000 steps), at least
-    # 8 timed launches in short ones; runs too short to sample time every launch between chained
-    # events (the cheaper way to time ALL launches).
-    period = max(1, min(16, args.steps // 8))
-    dm.set_timing(True, chained=period == 1, dispatch=period > 1, period=period)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
+    dm.set_timing(True, dispatch=True, period=period)
+    for _ in range(k_timed):
         step()
     fence()
-    elapsed = time.perf_counter() - t0
     dm.set_timing(False)
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
     n_r, ms_r = dm.kernel_time(capi.ALGO_RNEA)
     n_a, ms_a = dm.kernel_time(capi.ALGO_ABA)
     if not do_rnea:
@@ -319,10 +332,13 @@ def main():
                 "batch_per_gpu": B,
                 "evals_per_step_per_gpu": evals_per_step,
                 "rnea_kernel_ms": avg_r if do_rnea else None, "aba_kernel_ms": avg_a if do_aba else None,
-                "kernel_timing": {"how": ("begin / end timestamps of the dispatch (hipExtLaunchKernelGGL events on the "
-                                          "launch stream), one launch in `period` inside the timed region") if period > 1
-                                  else "chained hipEvents on the launch stream, every launch",
-                                  "period": period, "timed_launches": {"rnea": n_r, "aba": n_a}},
+                "repeats": len(regions),
+                "region_ms": {"median": elapsed * 1e3, "min": min(regions) * 1e3, "max": max(regions) * 1e3},
+                "kernel_timing": {"how": "separate region after the timed one (no event inside the timed region): "
+                                         f"{k_timed} more steps, one launch in {period} of each kernel with the dispatch's own "
+                                         "begin / end timestamps (hipExtLaunchKernelGGL events on the launch stream)",
+                                  "period": period,
+                                  "timed_launches": {"rnea": n_r, "aba": n_a}},
                 "rnea_evals_per_s_kernel": B / (avg_r * 1e-3) if avg_r > 0 else None,
                 "aba_evals_per_s_kernel": B / (avg_a * 1e-3) if avg_a > 0 else None,
                 "instance_major_evals_per_s": im_rate,

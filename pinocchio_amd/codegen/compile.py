@@ -20,16 +20,16 @@ from typing import Dict, Optional
 import numpy as np
 
 from .. import model as M
-from . import aba, deriv, fkjac, joints, minv, prod, rnea
+from . import aba, aba_local, deriv, fkjac, joints, minv, prod, rnea
 from .emit import AHEAD, Emitter, plan_storage
 
-ALGOS = {"rnea": rnea.generate, "aba": aba.generate, "fkjac": fkjac.generate, "deriv": deriv.generate,
+ALGOS = {"rnea": rnea.generate, "aba": aba.generate, "aba_local": aba_local.generate, "fkjac": fkjac.generate, "deriv": deriv.generate,
          "minv": minv.generate, "prod": prod.generate}
 
 # storage budgets (doubles per lane) of the park planner, per algorithm:
 # (registers for short-lived parks, LDS, registers for long-lived parks)
 # LDS: 160 KiB per CU, 4 resident waves of 64 lanes at one wave per SIMD -> 80 doubles per lane
-BUDGETS = {"rnea": (40, 80, 0), "aba": (48, 80, 100, 64), "fkjac": (36, 80, 0), "deriv": (64, 80, 32, 64),
+BUDGETS = {"rnea": (40, 80, 0), "aba": (48, 80, 100, 64), "aba_local": (48, 80, 100, 64), "fkjac": (36, 80, 0), "deriv": (64, 80, 32, 64),
            "minv": (64, 80, 64, 64), "prod": (0, 0, 0)}  # (deriv: first rung of LADDER)
 for _a in list(BUDGETS):  # experiment hook: BRBD_CG_ABA="64,80"
     _v = os.environ.get("BRBD_CG_" + _a.upper())
@@ -55,10 +55,11 @@ FINE = set(os.environ.get("BRBD_CG_FINE", "deriv,minv,prod").split(","))
 # the body's register-pressure estimate (doubles live in program order) fits: hipcc spills to
 # scratch beyond ~200 doubles (512 registers per lane at one wave per SIMD, minus addressing).
 LADDER = {"aba": [(48, 80, 100, 64), (32, 80, 100, 64), (16, 80, 100, 64), (16, 80, 80, 64)],
+          "aba_local": [(48, 80, 100, 64), (32, 80, 100, 64), (16, 80, 100, 64), (16, 80, 80, 64)],
           "deriv": [(64, 80, 32, 64), (40, 80, 32, 64), (24, 80, 16, 64), (8, 80, 0, 64), (0, 80, 0, 64),
                     (0, 80, 0, 48), (0, 80, 0, 24)],
           "minv": [(64, 80, 64, 64), (32, 80, 32, 64), (16, 80, 16, 64), (0, 80, 0, 64)]}
-LIVE_MAX = {"aba": 230, "deriv": 182, "minv": 200}
+LIVE_MAX = {"aba": 230, "aba_local": 230, "deriv": 182, "minv": 200}
 
 _IDENT = re.compile(r"\b([a-z][a-z]?_?[0-9]+(?:_[0-9]+)?|[sc]_t[0-9]+)\b")
 
@@ -96,8 +97,29 @@ class Kernel:
         self.lds, self.glb, self.stats, self.nvisits = lds, glb, stats, nvisits
 
 
+# ABA exists in both conventions of the reference (aba.hxx:102-294 WORLD, :378-542 LOCAL; same ddq,
+# unittest/aba.cpp:157-159): the compiler emits both and keeps the shorter program.
+ABA_CONVENTION = os.environ.get("BRBD_CG_ABA_CONV", "auto")  # auto | world | local
+
+
+def kernel_cost(k: "Kernel") -> int:
+    """Issue slots of a body, roughly: one per fp64 statement, ~35 per sincos / ~6 per rcp, rsqrt."""
+    return k.stats["fp"] + 30 * k.stats["trans"]
+
+
 def build_kernel(mv: joints.ModelView, algo: str, reg_budget: Optional[int] = None,
                  lds_budget: Optional[int] = None) -> Kernel:
+    if algo == "aba":
+        conv = {"world": ["aba"], "local": ["aba_local"]}.get(ABA_CONVENTION, ["aba", "aba_local"])
+        best = min((_build_one(mv, a, reg_budget, lds_budget) for a in conv), key=kernel_cost)
+        best.convention = "local" if best.algo == "aba_local" else "world"
+        best.algo = "aba"
+        return best
+    return _build_one(mv, algo, reg_budget, lds_budget)
+
+
+def _build_one(mv: joints.ModelView, algo: str, reg_budget: Optional[int] = None,
+               lds_budget: Optional[int] = None) -> Kernel:
     gen = ALGOS[algo]
     ahead = dict(AHEAD, **AHEAD_ALGO.get(algo, {}))
     dry = gen(mv, Emitter())

@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 cd "$R"
 OUT=$R/gpurun_out/pmc_$TAG
 mkdir -p "$OUT"
-ARGS="--steps 4 --warmup 2 --no-cpu-baseline $*"
+ARGS="--steps 4 --warmup 2 --repeats 1 --no-cpu-baseline $*"
 run() {
   local name=$1; shift
   timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -o p -- python3 bench.py $ARGS > "$OUT/$name.json" 2> "$OUT/$name.err" || { echo "pass $name failed"; tail -3 "$OUT/$name.err"; return 1; }

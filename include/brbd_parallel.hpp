@@ -321,6 +321,7 @@ inline ModelDesc make_desc(const pinocchio::Model& model) {
 #include <map>
 #include <memory>
 #include <mutex>
+#include <type_traits>
 #include <pinocchio/multibody/pool/model.hpp>
 namespace brbd {
 namespace detail {
@@ -363,22 +364,79 @@ inline void forget(const pinocchio::ModelPoolTpl<Scalar, Options, JointCollectio
   detail::pool_cache().erase(static_cast<const void*>(&pool));
 }
 
+// Argument adaptation.  The reference takes ANY Eigen::MatrixBase (parallel/rnea.hpp:39-45): plain
+// matrices, blocks, maps with strides, row-major matrices, expressions such as 2 * q.  The C ABI
+// wants column-major storage with unit inner stride (element (d, b) at x[b * ld + d]).  An argument
+// that already is that (DirectAccessBit, not row-major unless it is a column vector, inner stride 1 at
+// compile time) is passed through by reference; anything else is evaluated into a plain
+// column-major matrix first (inputs), or computed into one and assigned back (the output).
+namespace detail {
+typedef Eigen::Matrix<double, Eigen::Dynamic, Eigen::Dynamic, Eigen::ColMajor> PlainColMajor;
+template <class D>
+struct passes_through {
+  static const bool value = (int(Eigen::internal::traits<D>::Flags) & int(Eigen::DirectAccessBit)) != 0 &&
+                            (!bool(D::IsRowMajor) || int(D::ColsAtCompileTime) == 1) &&
+                            int(Eigen::internal::inner_stride_at_compile_time<D>::ret) == 1;
+};
+template <class D, bool Through = passes_through<D>::value>
+struct InArg {  // input: the argument itself
+  const D& m;
+  explicit InArg(const Eigen::MatrixBase<D>& x) : m(x.derived()) {}
+  const D& get() const { return m; }
+};
+template <class D>
+struct InArg<D, false> {  // input: evaluated copy (also turns row-major storage into column-major)
+  PlainColMajor m;
+  explicit InArg(const Eigen::MatrixBase<D>& x) : m(x) {}
+  const PlainColMajor& get() const { return m; }
+};
+template <class D, bool Through = passes_through<D>::value>
+struct OutArg {  // output written in place, through const like the reference's const_cast_derived()
+  D& m;
+  explicit OutArg(const Eigen::MatrixBase<D>& x) : m(x.const_cast_derived()) {}
+  D& get() { return m; }
+  void commit() {}
+};
+template <class D>
+struct OutArg<D, false> {  // output computed into a plain matrix, then assigned to the caller's expression
+  D& target;
+  PlainColMajor m;
+  explicit OutArg(const Eigen::MatrixBase<D>& x) : target(x.const_cast_derived()), m(x.rows(), x.cols()) {}
+  PlainColMajor& get() { return m; }
+  void commit() { target = m; }
+};
+}  // namespace detail
+
 // same template header as algorithm/parallel/rnea.hpp:31-45, for Scalar = double
 template <int Options, template <typename, int> class JointCollectionTpl, typename ConfigVectorPool,
           typename TangentVectorPool1, typename TangentVectorPool2, typename TangentVectorPool3>
 void rneaInParallel(const size_t num_threads, pinocchio::ModelPoolTpl<double, Options, JointCollectionTpl>& pool,
                     const Eigen::MatrixBase<ConfigVectorPool>& q, const Eigen::MatrixBase<TangentVectorPool1>& v,
                     const Eigen::MatrixBase<TangentVectorPool2>& a, const Eigen::MatrixBase<TangentVectorPool3>& tau) {
-  rneaInParallel(num_threads, detail::device_pool(pool), q.derived(), v.derived(), a.derived(),
-                 tau.const_cast_derived());
+  static_assert(std::is_same<typename ConfigVectorPool::Scalar, double>::value &&
+                    std::is_same<typename TangentVectorPool3::Scalar, double>::value,
+                "the MI355X engine computes in double");
+  detail::InArg<ConfigVectorPool> qe(q);
+  detail::InArg<TangentVectorPool1> ve(v);
+  detail::InArg<TangentVectorPool2> ae(a);
+  detail::OutArg<TangentVectorPool3> te(tau);
+  rneaInParallel(num_threads, detail::device_pool(pool), qe.get(), ve.get(), ae.get(), te.get());
+  te.commit();
 }
 template <int Options, template <typename, int> class JointCollectionTpl, typename ConfigVectorPool,
           typename TangentVectorPool1, typename TangentVectorPool2, typename TangentVectorPool3>
 void abaInParallel(const size_t num_threads, pinocchio::ModelPoolTpl<double, Options, JointCollectionTpl>& pool,
                    const Eigen::MatrixBase<ConfigVectorPool>& q, const Eigen::MatrixBase<TangentVectorPool1>& v,
                    const Eigen::MatrixBase<TangentVectorPool2>& tau, const Eigen::MatrixBase<TangentVectorPool3>& a) {
-  abaInParallel(num_threads, detail::device_pool(pool), q.derived(), v.derived(), tau.derived(),
-                a.const_cast_derived());
+  static_assert(std::is_same<typename ConfigVectorPool::Scalar, double>::value &&
+                    std::is_same<typename TangentVectorPool3::Scalar, double>::value,
+                "the MI355X engine computes in double");
+  detail::InArg<ConfigVectorPool> qe(q);
+  detail::InArg<TangentVectorPool1> ve(v);
+  detail::InArg<TangentVectorPool2> te(tau);
+  detail::OutArg<TangentVectorPool3> ae(a);
+  abaInParallel(num_threads, detail::device_pool(pool), qe.get(), ve.get(), te.get(), ae.get());
+  ae.commit();
 }
 }  // namespace brbd
 #endif

@@ -38,7 +38,9 @@ from . import joints as J
 from .aba import chol_factor, chol_solve, find_tails, spd_inverse, sym6_full
 from .emit import ONE, ZERO, Emitter, V, num
 
-TAIL = int(os.environ.get("BRBD_CG_LTAIL", "2"))
+TAIL = int(os.environ.get("BRBD_CG_LTAIL", "2"))  # default tail length (compile.py walks a ladder of them)
+# tail joints: keep (sin, cos) from pass 1 for pass 3's re-run (2 doubles per tail joint) or evaluate again
+TAIL_PARK_SC = os.environ.get("BRBD_CG_LTAILSC", "0") == "1"
 # pass 3 needs the bias c_i = v_i x S vq again: parked with the hand-off record (4 doubles for an
 # axis-aligned revolute joint) or rebuilt from the velocity recursion (~20 instructions)
 PARK_BIAS = os.environ.get("BRBD_CG_LBIAS", "0") == "1"
@@ -103,22 +105,26 @@ def unit_axis(col: List[V]):
     return None
 
 
-def generate(mv: J.ModelView, e: Emitter) -> Emitter:
+def generate(mv: J.ModelView, e: Emitter, tail: int = None) -> Emitter:
     keep = {}     # joint -> Park of what its backward visit needs from its forward visit
     hand = {}     # joint -> Park of UDinv (6 nv) + k (nv) [+ bias] [+ (s, c)]
     contrib = {}  # joint -> Park of the sum of the finished children's (Ia 21, pA 6) in its frame
-    tails = find_tails(mv, TAIL)
+    tailsc = {}   # tail joint -> Park of (s, c)
+    tails = find_tails(mv, TAIL if tail is None else tail)
     in_tail = {j for ch in tails.values() for j in ch}
 
     def transform(i, sc=None):
         R, t, sc = J.joint_transform(e, mv, i, sc=sc)
         return R, t, sc
 
-    def joint_velocity(i):
+    def joint_velocity(i, vq=None):
+        """S, S vq and vq itself (read from the boundary matrix unless a parked copy is at hand:
+        every re-read is HBM traffic again, the inputs stream past the L2)"""
         S = J.subspace(e, mv, i)
         iv = mv.idx_v[i]
-        vq = [e.inp("V", iv + k) for k in range(mv.nv(i))]
-        return S, J.s_times(e, S, vq)
+        if vq is None:
+            vq = [e.inp("V", iv + k) for k in range(mv.nv(i))]
+        return S, J.s_times(e, S, vq), list(vq)
 
     def body_terms(i, v, vJ):
         """bias c = v x vJ (aba.hxx:398), Ia = Y.matrix() (:400), pA = v x* (Y v) (:401-402)"""
@@ -230,8 +236,8 @@ def generate(mv: J.ModelView, e: Emitter) -> Emitter:
             if k == 0:
                 vals = e.unpark(kin_parent)
                 vp, a_head = vals[0:6], vals[6:12]
-            R, t, sc = transform(i)
-            S, vJ = joint_velocity(i)
+            R, t, sc = transform(i, tuple(e.unpark(tailsc[i])) if i in tailsc else None)
+            S, vJ, _ = joint_velocity(i)
             v = A.vadd(e, A.actinv_motion(e, R, t, vp), vJ)
             vp = v
             if leaf:
@@ -295,17 +301,20 @@ def generate(mv: J.ModelView, e: Emitter) -> Emitter:
             UD = [h[6 * k:6 * k + 6] for k in range(nv)]
             kk = h[6 * nv:7 * nv]
             pos = 7 * nv
-            bias = None
+            bias = vq = None
             if PARK_BIAS:
                 bias = h[pos:pos + 6]
                 pos += 6
+            else:
+                vq = h[pos:pos + nv]
+                pos += nv
             sc = tuple(h[pos:pos + 2]) if len(h) >= pos + 2 else None
             R, t, _ = transform(i, sc)
             S = J.subspace(e, mv, i)
             leaf = not mv.children[i]
             v = None
             if bias is None or not leaf:  # (the velocity also goes down to the children: tails start from it)
-                _, vJ = joint_velocity(i)
+                _, vJ, _ = joint_velocity(i, vq)
                 v = A.vadd(e, A.actinv_motion(e, R, t, vp), vJ)
                 if bias is None:
                     bias = A.motion_cross(e, v, vJ)
@@ -322,18 +331,19 @@ def generate(mv: J.ModelView, e: Emitter) -> Emitter:
             leaf = not mv.children[i]
             e.begin_visit("FWD %d%s" % (i, " + BWD (leaf)" if leaf else ""))
             R, t, sc = transform(i)
-            S, vJ = joint_velocity(i)
+            S, vJ, vq = joint_velocity(i)
             v = vJ if p == 0 else A.vadd(e, A.actinv_motion(e, R, t, cur), vJ)  # aba.hxx:394-396
             cur = v
             if not leaf:
-                if sc is not None:
-                    keep[i] = e.park(list(sc), "stack")
+                keep[i] = e.park(vq + (list(sc) if sc is not None else []), "stack")
                 for c in sorted(mv.children[i], reverse=True):
                     walk(c)
                 e.begin_visit("BWD %d" % i)
                 v = cur
-                R, t, sc = transform(i, tuple(e.unpark(keep[i])) if i in keep else None)
-                S, vJ = joint_velocity(i)
+                kept = e.unpark(keep[i])
+                vq = kept[:mv.nv(i)]
+                R, t, sc = transform(i, tuple(kept[mv.nv(i):]) if sc is not None else None)
+                S, vJ, _ = joint_velocity(i, vq)
             bias, Ia, pA = body_terms(i, v, vJ)
             if i in contrib:
                 vals = e.unpark(contrib.pop(i))
@@ -344,11 +354,12 @@ def generate(mv: J.ModelView, e: Emitter) -> Emitter:
             UD, kk, acc = project(i, S, bias, Ia, pA)
             if i not in in_tail:
                 rec = [x for col in UD for x in col] + kk
-                if PARK_BIAS:
-                    rec += bias
+                rec += bias if PARK_BIAS else vq
                 if sc is not None and not RECOMPUTE_SINCOS:
                     rec += list(sc)
                 hand[i] = e.park(rec, "hand")
+            elif TAIL_PARK_SC and sc is not None:
+                tailsc[i] = e.park(list(sc), "hand")
             to_parent(i, R, t, acc)
             cur = A.act_motion(e, R, t, A.vsub(e, v, vJ))  # step back onto the parent
             return None

@@ -140,7 +140,8 @@ def _emit_algo(args):
                 "}  // namespace spec_%s" % ident,
                 "}  // namespace brbd",
                 ""]))
-    gather = ", ".join("%d,%d,%d" % (j, FIELD[f], i) for (j, f, i) in k.const_list) or "0"
+    from .emit import encode_const
+    gather = ", ".join("%d,%d,%d,%d" % encode_const(ident, FIELD) for ident in k.const_list) or "0"
     return algo, gather, len(k.const_list), k.lds, k.glb, stage_rows, layouts
 
 

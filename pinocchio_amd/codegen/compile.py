@@ -21,7 +21,7 @@ import numpy as np
 
 from .. import model as M
 from . import aba, aba_local, deriv, fkjac, joints, minv, prod, rnea
-from .emit import AHEAD, Emitter, plan_storage
+from .emit import AHEAD, Emitter, eval_const_expr, plan_storage
 
 ALGOS = {"rnea": rnea.generate, "aba": aba.generate, "aba_local": aba_local.generate, "fkjac": fkjac.generate, "deriv": deriv.generate,
          "minv": minv.generate, "prod": prod.generate}
@@ -59,7 +59,7 @@ LADDER = {"aba": [(48, 80, 100, 64), (32, 80, 100, 64), (16, 80, 100, 64), (16, 
           "deriv": [(64, 80, 32, 64), (40, 80, 32, 64), (24, 80, 16, 64), (8, 80, 0, 64), (0, 80, 0, 64),
                     (0, 80, 0, 48), (0, 80, 0, 24)],
           "minv": [(64, 80, 64, 64), (32, 80, 32, 64), (16, 80, 16, 64), (0, 80, 0, 64)]}
-LIVE_MAX = {"aba": 230, "aba_local": 230, "deriv": 182, "minv": 200}
+LIVE_MAX = {"aba": 230, "aba_local": int(os.environ.get("BRBD_CG_LIVEMAX", "240")), "deriv": 182, "minv": 200}
 
 _IDENT = re.compile(r"\b([a-z][a-z]?_?[0-9]+(?:_[0-9]+)?|[sc]_t[0-9]+)\b")
 
@@ -118,29 +118,59 @@ def build_kernel(mv: joints.ModelView, algo: str, reg_budget: Optional[int] = No
     return _build_one(mv, algo, reg_budget, lds_budget)
 
 
+# aba_local: (tail length, budgets) in order of preference.  Anything parked in the wave's global
+# area costs more than a longer tail (MI355X, humanoid: 40 doubles per lane in global parks 29.3 us,
+# none 25.1 us; tails of 3 instead of 2 joints 26.2 us), so the first rung that keeps every park on
+# chip within the register estimate wins.
+LADDER_LOCAL = [(t, b) for t in (2, 3, 4, 5) for b in ((64, 80, 140, 64), (48, 80, 140, 64), (48, 80, 120, 64), (48, 80, 100, 64))]
+
+
 def _build_one(mv: joints.ModelView, algo: str, reg_budget: Optional[int] = None,
                lds_budget: Optional[int] = None) -> Kernel:
     gen = ALGOS[algo]
     ahead = dict(AHEAD, **AHEAD_ALGO.get(algo, {}))
-    dry = gen(mv, Emitter())
-    ladder = [BUDGETS[algo]]
+    ladder = [(None, BUDGETS[algo])]
     if reg_budget is None and lds_budget is None and ("BRBD_CG_" + algo.upper()) not in os.environ:
-        ladder = LADDER.get(algo, ladder)
-    for budget in ladder:
+        if algo == "aba_local" and "BRBD_CG_LTAIL" not in os.environ:
+            ladder = LADDER_LOCAL
+        else:
+            ladder = [(None, b) for b in LADDER.get(algo, [BUDGETS[algo]])]
+    dry, best = {}, None
+    for tail, budget in ladder:
+        kw = {} if tail is None else {"tail": tail}
+        if tail not in dry:
+            dry[tail] = gen(mv, Emitter(), **kw)
         rb, lb, rl = budget[:3]
         rt = budget[3] if len(budget) > 3 else 64
         rb = rb if reg_budget is None else reg_budget
         lb = lb if lds_budget is None else lds_budget
-        plan, lds, glb = plan_storage(dry.parks, rb, lb, rl, rt, strict=(algo == "minv"))
-        e = gen(mv, Emitter(plan))
+        plan, lds, glb = plan_storage(dry[tail].parks, rb, lb, rl, rt, strict=(algo == "minv"))
+        e = gen(mv, Emitter(plan), **kw)
         text = e.text(ahead, algo in FINE)
-        if len(ladder) == 1 or liveness_peak(text) <= LIVE_MAX[algo]:
-            break
-    return Kernel(algo, text, list(e.const_list), lds, glb, dict(e.stats), len(e.visits))
+        k = Kernel(algo, text, list(e.const_list), lds, glb, dict(e.stats), len(e.visits))
+        if len(ladder) == 1:
+            return k
+        fits = liveness_peak(text) <= LIVE_MAX[algo]
+        if algo != "aba_local":
+            best = k
+            if fits:
+                break
+            continue
+        if fits and glb == 0:
+            return k
+        if fits and (best is None or glb < best.glb):
+            best = k
+    return best if best is not None else k
 
 
 def pack_constants(mv: joints.ModelView, const_list) -> np.ndarray:
-    return np.array([mv.value(ident) for ident in const_list] + [0.0], dtype=np.float64)
+    """The packed constant table: model constants (joint, field, index) and the expressions of
+    earlier entries the emitter hoisted out of the body (emit.eval_const_expr)."""
+    vals = []
+    for ident in const_list:
+        vals.append(eval_const_expr(ident, vals) if ident[0] == "expr" else
+                    (ident[1] if ident[0] == "lit" else mv.value(ident)))
+    return np.array(vals + [0.0], dtype=np.float64)
 
 
 _CPU_SHELL = r"""

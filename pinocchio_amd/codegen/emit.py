@@ -83,7 +83,7 @@ def _lit(x: float) -> str:
 
 
 # prefetch distance in statements per kind of early load (experiment hook: BRBD_CG_AHEAD="in=800")
-AHEAD = {"ct": 60, "in": 400, "lds": 0, "glb": 400}
+AHEAD = {"ct": 60, "in": 400, "inf": 100, "lds": 0, "glb": 400}
 for _kv in os.environ.get("BRBD_CG_AHEAD", "").split(","):
     if "=" in _kv:
         AHEAD[_kv.split("=")[0]] = int(_kv.split("=")[1])
@@ -93,6 +93,52 @@ _DECL = re.compile(r"(?:const )?double ([^=;]+?)(?: =|;)")
 
 ZERO = V(num=0.0)
 ONE = V(num=1.0)
+
+# Expressions of model constants alone are evaluated on the host (experiment hook: BRBD_CG_HOIST=0)
+HOIST_CONST = os.environ.get("BRBD_CG_HOIST", "1") == "1"
+# ... while the visit has fewer than this many table entries: they travel in SGPR pairs, about 30 of
+# which are free next to the buffer resources; hipcc spills the rest into VGPR lanes
+HOIST_CAP = int(os.environ.get("BRBD_CG_HOISTCAP", "24"))
+_KNAME = re.compile(r"-?k[0-9]+$")
+
+
+def _is_const(x) -> bool:
+    return not isinstance(x, str) or _KNAME.match(x) is not None
+
+
+CONST_OPS = {"mul": 0, "add": 1, "fma": 2, "rcp": 3, "rsqrt": 4}
+
+
+def eval_const_expr(ident, values) -> float:
+    """Value of a hoisted constant expression ("expr", op, (index, negated)...) given the values of
+    the table entries before it.  csrc/brbd_capi.hip: pack_constants evaluates the same program."""
+    op, a = ident[1], [(-values[i] if neg else values[i]) for i, neg in ident[2:]]
+    if op == "mul":
+        return a[0] * a[1]
+    if op == "add":
+        return a[0] + a[1]
+    if op == "fma":
+        return a[0] * a[1] + a[2]
+    if op == "rcp":
+        return 1.0 / a[0]
+    if op == "rsqrt":
+        return 1.0 / math.sqrt(a[0])
+    raise KeyError(op)
+
+
+def encode_const(ident, field_codes) -> Tuple[int, int, int, int]:
+    """One entry of a kernel's gather list (csrc/brbd_spec.hpp: SpecKernel::gather): a model constant
+    (field, joint, index, 0), a literal (15, low word, high word, 0) or an expression of earlier
+    entries (16 + op, operands as 2 * index + negated)."""
+    import struct
+    if ident[0] == "lit":
+        lo, hi = struct.unpack("<ii", struct.pack("<d", ident[1]))
+        return (15, lo, hi, 0)
+    if ident[0] == "expr":
+        r = [2 * i + (1 if neg else 0) for i, neg in ident[2:]] + [0, 0]
+        return (16 + CONST_OPS[ident[1]], r[0], r[1], r[2])
+    j, f, i = ident
+    return (field_codes[f], j, i, 0)
 
 
 def num(x: float) -> V:
@@ -131,6 +177,7 @@ class Emitter:
         self.stats = {"fp": 0, "ld": 0, "st": 0, "ct": 0, "trans": 0}
         self.has_blocks = False
         self.fillers: List[str] = []  # stores that depend on nothing (structural zeros)
+        self.lit_index: Dict[float, int] = {}
         self.opaque_regs = False  # experiment: made register pressure worse with hipcc 7.2
 
     # ---- visits --------------------------------------------------------------------------
@@ -187,7 +234,9 @@ class Emitter:
         if key in self.in_cache:
             return self.in_cache[key]
         name = "%s%d_%d" % (which.lower(), k, self.vi)
-        self.pre("const double %s = IN_%s(%d);" % (name, which, k), "in")
+        # (external forces: 6 more loads per joint, only live in the fext kernel variants, which are the
+        # ones closest to the register limit: a shorter prefetch distance keeps fewer of them in flight)
+        self.pre("const double %s = IN_%s(%d);" % (name, which, k), "inf" if which == "F" else "in")
         self.stats["ld"] += 1
         v = V(name)
         self.in_cache[key] = v
@@ -249,9 +298,33 @@ class Emitter:
         self.stats["st"] += 1
 
     # ---- arithmetic with folding -------------------------------------------------------------
-    def _emit(self, key: tuple, expr: str, neg: bool = False, kind: str = "fp") -> V:
+    def _emit(self, key: tuple, expr: str, neg: bool = False, kind: str = "fp", cdef=None) -> V:
         if key in self.cse:
             v = self.cse[key]
+            return -v if neg else v
+        if (cdef is not None and HOIST_CONST and all(_is_const(x) for x in cdef[1])
+                and sum(1 for p in self.visits[-1].pre if p[1] == "ct") < HOIST_CAP):
+            # every operand is a model constant (or a literal): the value is one too.  It becomes an
+            # entry of the packed constant table, evaluated once on the host (brbd_model_create)
+            # instead of once per wave per launch.
+            refs = []
+            for x in cdef[1]:
+                if isinstance(x, str):
+                    refs.append((int(x.lstrip("-")[1:]), x[0] == "-"))
+                else:  # a literal operand is a table entry of its own (never loaded by the kernel)
+                    if float(x) not in self.lit_index:
+                        self.lit_index[float(x)] = len(self.const_list)
+                        self.const_list.append(("lit", float(x)))
+                    refs.append((self.lit_index[float(x)], False))
+            ident = ("expr", cdef[0]) + tuple(refs)
+            k = len(self.const_list)
+            self.const_list.append(ident)
+            name = "k%d" % k
+            self.pre("const double %s = CT(%d);" % (name, k))
+            self.stats["ct"] += 1
+            self.stats["hoisted"] = self.stats.get("hoisted", 0) + 1
+            v = V(name)
+            self.cse[key] = v
             return -v if neg else v
         name = self._tmp()
         self.stmt("const double %s = %s;" % (name, expr))
@@ -274,10 +347,10 @@ class Emitter:
                 return -a
             neg = a.neg != (b.num < 0)
             c = abs(b.num)
-            return self._emit(("*", a.name, ("#", c)), "%s * %s" % (a.name, _lit(c)), neg)
+            return self._emit(("*", a.name, ("#", c)), "%s * %s" % (a.name, _lit(c)), neg, cdef=("mul", [a.name, c]))
         neg = a.neg != b.neg
         x, y = sorted((a.name, b.name))
-        return self._emit(("*", x, y), "%s * %s" % (x, y), neg)
+        return self._emit(("*", x, y), "%s * %s" % (x, y), neg, cdef=("mul", [x, y]))
 
     def add(self, a: V, b: V) -> V:
         if a.is_num and b.is_num:
@@ -290,19 +363,20 @@ class Emitter:
             a, b = b, a
         if b.is_num:  # var + literal
             if a.neg:  # -(x) + c = -(x - c)
-                return self._emit(("+#", a.name, -b.num), "%s + %s" % (a.name, _lit(-b.num)), True)
-            return self._emit(("+#", a.name, b.num), "%s + %s" % (a.name, _lit(b.num)))
+                return self._emit(("+#", a.name, -b.num), "%s + %s" % (a.name, _lit(-b.num)), True,
+                                  cdef=("add", [a.name, -b.num]))
+            return self._emit(("+#", a.name, b.num), "%s + %s" % (a.name, _lit(b.num)), cdef=("add", [a.name, b.num]))
         if a.neg and b.neg:
             x, y = sorted((a.name, b.name))
-            return self._emit(("+", x, y), "%s + %s" % (x, y), True)
+            return self._emit(("+", x, y), "%s + %s" % (x, y), True, cdef=("add", [x, y]))
         if not a.neg and not b.neg:
             x, y = sorted((a.name, b.name))
-            return self._emit(("+", x, y), "%s + %s" % (x, y))
+            return self._emit(("+", x, y), "%s + %s" % (x, y), cdef=("add", [x, y]))
         if a.neg:
             a, b = b, a  # a positive, b negative: a - b
         if a.name == b.name:
             return ZERO
-        return self._emit(("-", a.name, b.name), "%s - %s" % (a.name, b.name))
+        return self._emit(("-", a.name, b.name), "%s - %s" % (a.name, b.name), cdef=("add", [a.name, "-" + b.name]))
 
     def sub(self, a: V, b: V) -> V:
         return self.add(a, -b)
@@ -325,13 +399,16 @@ class Emitter:
         else:
             cneg, cx = c.neg, c.name
         x, y = (a.name, bx) if b.is_num else tuple(sorted((a.name, bx)))
+        yv = abs(b.num) if b.is_num else y
+        cv = abs(c.num) if c.is_num else cx
         if pneg and cneg:
-            return self._emit(("fma", x, y, cx, 0), "FMA(%s, %s, %s)" % (x, y, cx), True)
+            return self._emit(("fma", x, y, cx, 0), "FMA(%s, %s, %s)" % (x, y, cx), True, cdef=("fma", [x, yv, cv]))
         if not pneg and not cneg:
-            return self._emit(("fma", x, y, cx, 0), "FMA(%s, %s, %s)" % (x, y, cx))
+            return self._emit(("fma", x, y, cx, 0), "FMA(%s, %s, %s)" % (x, y, cx), cdef=("fma", [x, yv, cv]))
         if pneg:  # -x*y + c
-            return self._emit(("fma", x, y, cx, 1), "FMA(-%s, %s, %s)" % (x, y, cx))
-        return self._emit(("fma", x, y, cx, 1), "FMA(-%s, %s, %s)" % (x, y, cx), True)  # x*y - c = -(-x*y + c)
+            return self._emit(("fma", x, y, cx, 1), "FMA(-%s, %s, %s)" % (x, y, cx), cdef=("fma", ["-" + x, yv, cv]))
+        return self._emit(("fma", x, y, cx, 1), "FMA(-%s, %s, %s)" % (x, y, cx), True,
+                          cdef=("fma", ["-" + x, yv, cv]))  # x*y - c = -(-x*y + c)
 
     def dot(self, a: Sequence[V], b: Sequence[V], init: V = ZERO) -> V:
         """init + sum a_k b_k as an FMA chain (terms with an exact zero factor vanish)."""
@@ -343,11 +420,11 @@ class Emitter:
     def rcp(self, a: V) -> V:
         if a.is_num:
             return num(1.0 / a.num)
-        return self._emit(("rcp", a.name), "RCP(%s)" % a.name, a.neg, "trans")
+        return self._emit(("rcp", a.name), "RCP(%s)" % a.name, a.neg, "trans", cdef=("rcp", [a.name]))
 
     def rsqrt(self, a: V) -> V:
         assert not a.is_num and not a.neg
-        return self._emit(("rsq", a.name), "RSQRT(%s)" % a.name, False, "trans")
+        return self._emit(("rsq", a.name), "RSQRT(%s)" % a.name, False, "trans", cdef=("rsqrt", [a.name]))
 
     def sincos(self, a: V) -> Tuple[V, V]:
         if a.is_num:

@@ -9,6 +9,7 @@
 #include <hip/hip_ext.h>
 #include <dlfcn.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -167,10 +168,33 @@ std::string model_signature(const FlatModel& F, bool dense) {
   }
   return s;
 }
+// A kernel's packed constant table from its gather list (codegen/emit.py: encode_const), 4 ints per
+// entry: a model constant (field, joint, index, 0); a literal (15, low word, high word, 0); or an
+// expression of EARLIER entries that the model compiler hoisted out of the kernel body (16 + op,
+// operands as 2 * index + negated; op 0 a*b, 1 a+b, 2 a*b+c, 3 1/a, 4 1/sqrt(a)) -- e.g. the 6 x 6
+// matrix of a body inertia, or a leaf joint's whole articulated-body projection, evaluated once here
+// instead of once per wave per launch.
 std::vector<double> pack_constants(const FlatModel& F, const SpecKernel& k) {
   std::vector<double> ct((size_t)k.nconst + 16, 0.0);  // padded: merged s_loads may read past the end
-  for (int c = 0; c < k.nconst; ++c)
-    ct[c] = model_constant(F, k.gather[3 * c], k.gather[3 * c + 1], k.gather[3 * c + 2]);
+  auto ref = [&](int32_t r) { const double x = ct[(size_t)(r >> 1)]; return (r & 1) ? -x : x; };
+  for (int c = 0; c < k.nconst; ++c) {
+    const int32_t* g = k.gather + 4 * c;
+    if (g[0] < 15) {
+      ct[c] = model_constant(F, g[1], g[0], g[2]);
+    } else if (g[0] == 15) {
+      const uint64_t bits = (uint64_t)(uint32_t)g[1] | ((uint64_t)(uint32_t)g[2] << 32);
+      std::memcpy(&ct[c], &bits, sizeof(double));
+    } else {
+      const double a = ref(g[1]);
+      switch (g[0] - 16) {
+        case 0: ct[c] = a * ref(g[2]); break;
+        case 1: ct[c] = a + ref(g[2]); break;
+        case 2: ct[c] = a * ref(g[2]) + ref(g[3]); break;
+        case 3: ct[c] = 1.0 / a; break;
+        default: ct[c] = 1.0 / std::sqrt(a); break;
+      }
+    }
+  }
   return ct;
 }
 

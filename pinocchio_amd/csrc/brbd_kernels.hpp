@@ -9,14 +9,10 @@
 //     child->parent in registers;
 //   * every control decision (op kind, joint kind, flags) is wave-uniform: no divergence.
 //
-// Each algorithm is ONE step function (`*_step`) instantiated twice:
-//   * generic kernels interpret the program at run time (any model; the live path state is kept
-//     in a wave-private, coalesced global workspace: GlobalStore);
-//   * static kernels (brbd_static.hpp) unroll a compile-time program for a registered topology:
-//     flags, joint kinds and stack slots fold to constants, the live path state becomes registers
-//     (RegStore) and the whole recursion is one straight-line instruction stream the compiler can
-//     schedule (loads hoisted far ahead of use), which is what hides HBM latency at one wave per
-//     SIMD (batch 65536 = exactly 1024 waves on 1024 SIMDs).
+// These are the TABLE-DRIVEN kernels: they interpret the program at run time for any model; the
+// live path state is kept in LDS and a wave-private, coalesced global workspace.  Models registered
+// at build time (or through a kernel plugin) run on the model-compiled kernels instead
+// (brbd_spec.hpp + pinocchio_amd/codegen): the same recursions as straight-line code.
 //
 // Reference recursions: algorithm/rnea.hxx:45-161, algorithm/aba.hxx:102-294,
 // algorithm/kinematics.hxx:52-97, algorithm/jacobian.hxx:38-95.

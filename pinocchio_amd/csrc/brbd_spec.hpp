@@ -26,7 +26,7 @@ struct SpecKernel {
   // dimensions, staged through LDS (RNEA / ABA only); variant: fkjac output mask (1 = J, 2 = oMi),
   // else index into codegen/build.py: WANTS
   SpecFn fn[3][4];
-  const int32_t* gather;  // nconst x (joint, field, index): how to pack the constant table
+  const int32_t* gather;  // nconst x 4 ints: how to pack the constant table (brbd_capi.hip: pack_constants)
   int32_t nconst;
   int32_t lds_doubles;    // per lane
   int32_t glb_doubles;    // per lane
@@ -37,7 +37,7 @@ enum : int { SF_R = 0, SF_T, SF_M, SF_C, SF_I, SF_ARM, SF_AXIS, SF_G };
 // Layout version of KArgs / SpecKernel / SpecEntry: kernels compiled separately (plugins built by
 // pinocchio_amd/codegen/plugin.py for models unknown when the library was built, loaded with
 // brbd_load_compiled_kernels) must agree with the library that launches them.
-#define BRBD_SPEC_ABI 5
+#define BRBD_SPEC_ABI 6
 
 struct SpecEntry {
   const char* name;

@@ -8,6 +8,8 @@
   fixed-joint merging, rpy placements and prismatic fingers.
 * ``manipulator()``      -- restatement of ``buildModels::manipulator``
   (``include/pinocchio/multibody/sample-models.hxx:57-141,222-226``) as data.
+* ``humanoid()``         -- restatement of ``buildModels::humanoid`` (``sample-models.hxx:312-405``,
+  free-flyer root): the reference's fully deterministic test humanoid, FF + 28 revolute, nq 35 / nv 34.
 * ``arm7()``             -- Franka-Panda-class 7-dof RZ chain (stand-in: the real URDF is
   not available offline; kinematics follow the public DH table, inertias synthetic).
 * ``quadruped()``        -- ANYmal-class FF + 4 x (RX, RY, RY), nq 19 / nv 18 (stand-in).
@@ -80,6 +82,47 @@ def manipulator() -> M.Model:
     for jt, P, Y, name in spec:
         parent = m.addJoint(parent, jt, P, name + "_joint")
         m.inertias[parent] = Y  # sample-models.hxx:86 overwrites the random inertia
+    return m
+
+
+def humanoid() -> M.Model:
+    """buildModels::humanoid(model, usingFF = true) (sample-models.hxx:312-405): free-flyer root with
+    Ijoint; two legs = addManipulator (sample-models.hxx:57-141) at SE3(rotate(pi, X), (0, -+0.2, -0.1))
+    whose last joint placement gets the rotation rotate(pi/2, Y) (:362-365); chest RX (Ijoint), RY
+    (Iarm); head RX at (0, 0, 1) (Ijoint), RY (Iarm); two arms = addManipulator on the chest at
+    SE3(rotate(pi, X), (0, -+0.3, 1)).  rotate() is Eigen's AngleAxis::toRotationMatrix: with
+    cos(pi) = -1, sin(pi) = 1.2e-16 it gives the same entries as the plain axis rotations below."""
+    m = M.Model("humanoid")
+    Ijoint = M.Inertia(0.1, np.zeros(3), np.eye(3) * 0.01)
+    Iarm = M.Inertia(1.0, np.array([0, 0, 0.5]), np.eye(3))
+    Marm = _T(t=(0, 0, 1))
+    Id = np.eye(4)
+
+    def add(parent, jt, P, Y, name):
+        j = m.addJoint(parent, jt, P, name + "_joint")
+        m.inertias[j] = Y
+        return j
+
+    def add_manipulator(root, Mroot, pre):
+        j = root
+        for jt, P, Y, name in ((M.JOINT_RX, Mroot, Ijoint, "shoulder1"), (M.JOINT_RY, Id, Ijoint, "shoulder2"),
+                               (M.JOINT_RZ, Id, Iarm, "shoulder3"), (M.JOINT_RY, Marm, Iarm, "elbow"),
+                               (M.JOINT_RX, Marm, Ijoint, "wrist1"), (M.JOINT_RY, Id, Iarm, "wrist2")):
+            j = add(j, jt, P, Y, pre + name)
+        return j
+
+    ff = add(0, M.JOINT_FREEFLYER, Id, Ijoint, "root")
+    add_manipulator(ff, _T(_rotx(np.pi), (0, -0.2, -0.1)), "rleg_")
+    add_manipulator(ff, _T(_rotx(np.pi), (0, 0.2, -0.1)), "lleg_")
+    for foot in (7, 13):  # :362-365
+        m.jointPlacements[foot][:3, :3] = _roty(np.pi / 2)
+    c1 = add(ff, M.JOINT_RX, Id, Ijoint, "chest1")
+    chest = add(c1, M.JOINT_RY, Id, Iarm, "chest2")
+    h1 = add(chest, M.JOINT_RX, Marm, Ijoint, "head1")
+    add(h1, M.JOINT_RY, Id, Iarm, "head2")
+    add_manipulator(chest, _T(_rotx(np.pi), (0, -0.3, 1.0)), "rarm_")
+    add_manipulator(chest, _T(_rotx(np.pi), (0, 0.3, 1.0)), "larm_")
+    assert (m.nq, m.nv, m.njoints) == (35, 34, 30)
     return m
 
 
@@ -226,6 +269,7 @@ BUILTIN = {
     "simple_humanoid": simple_humanoid,
     "baxter_simple": baxter_simple,
     "manipulator": manipulator,
+    "humanoid": humanoid,
     "arm7": arm7,
     "quadruped": quadruped,
     "talos_like": talos_like,

@@ -9,7 +9,7 @@ from pinocchio_amd import sample_models as S
 from util import rel_err_cols
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-NAMES = ["simple_humanoid", "manipulator", "arm7", "quadruped", "talos_like", "baxter_simple"]
+NAMES = ["simple_humanoid", "manipulator", "humanoid", "arm7", "quadruped", "talos_like", "baxter_simple"]
 
 
 @pytest.mark.parametrize("name", NAMES)

@@ -52,7 +52,6 @@ def test_full_size_talos_class_aba_one_gpu_slice():
     Br = B - 4097
     ddq_r = parallel.abaInParallel(1, pool, q[:, :Br], v[:, :Br], tau[:, :Br])
     assert torch.equal(ddq_r, ddq[:, :Br])
-    # (4) the chunked path really ran: force small chunks and compare
     pool.release()
 
 

@@ -64,7 +64,7 @@ def test_all_algorithms_vs_oracle_host_memspace(model, order):
     pool.release()
 
 
-@pytest.mark.parametrize("name", ["simple_humanoid", "manipulator", "arm7", "quadruped", "talos_like", "baxter_simple"])
+@pytest.mark.parametrize("name", ["simple_humanoid", "manipulator", "humanoid", "arm7", "quadruped", "talos_like", "baxter_simple"])
 def test_golden_vectors(name):
     g = np.load(os.path.join(GOLD, name + ".npz"))
     pool = parallel.ModelPool(S.build(name), 1)
@@ -317,7 +317,7 @@ def test_transposes_and_kernel_timing(torch_mod):
 
 
 # ---- model-compiled kernels (pinocchio_amd/codegen, csrc/brbd_spec.hpp) --------------------------
-BUILTIN_NAMES = ["simple_humanoid", "manipulator", "arm7", "quadruped", "talos_like", "baxter_simple"]
+BUILTIN_NAMES = ["simple_humanoid", "manipulator", "humanoid", "arm7", "quadruped", "talos_like", "baxter_simple"]
 
 
 def _perturbed(model):
@@ -372,8 +372,8 @@ def test_kernel_selection_pattern_dense_table(name):
     model = S.build(name)
     pool = parallel.ModelPool(model, 1)
     dm = pool.device_model(0)
-    # baxter_simple is not registered by default (codegen/build.py: REGISTERED)
-    assert dm.compiled_kernels() == (name + "_p" if name != "baxter_simple" else "")
+    # baxter_simple and the reference's test humanoid are not registered by default (codegen/build.py: REGISTERED)
+    assert dm.compiled_kernels() == (name + "_p" if name not in ("baxter_simple", "humanoid") else "")
     O = oracle.Oracle(model)
     _check_all(pool, model, O)
     dm.use_compiled(False)

@@ -29,7 +29,7 @@ def parity_models():
     joint kinds, with and without free-flyer root / armature, including multi-root forests."""
     kinds = [M.JOINT_RX, M.JOINT_RY, M.JOINT_RZ, M.JOINT_PX, M.JOINT_PY, M.JOINT_PZ, M.JOINT_SPHERICAL,
              M.JOINT_RUBX, M.JOINT_RUBY, M.JOINT_RUBZ, M.JOINT_FREEFLYER]
-    out = [S.simple_humanoid(), S.manipulator(), S.arm7(), S.quadruped(), S.talos_like(), S.baxter_simple()]
+    out = [S.simple_humanoid(), S.manipulator(), S.humanoid(), S.arm7(), S.quadruped(), S.talos_like(), S.baxter_simple()]
     for s in range(8):
         out.append(S.random_tree(100 + s, 8 + s, kinds=kinds if s % 2 else None,
                                  root_kind=(M.JOINT_FREEFLYER if s % 3 else None),

@@ -29,7 +29,8 @@ def rel(x, y):
 def main():
     out = os.path.join(ROOT, "tests", "golden")
     os.makedirs(out, exist_ok=True)
-    for name in ("simple_humanoid", "manipulator", "arm7", "quadruped", "talos_like", "baxter_simple"):
+    names = sys.argv[1:] or ("simple_humanoid", "manipulator", "humanoid", "arm7", "quadruped", "talos_like", "baxter_simple")
+    for name in names:  # (name some models on the command line to regenerate only those)
         m = S.build(name)
         O, T = oracle.Oracle(m), N.Tables(m)
         rng = np.random.default_rng(2025)

@@ -124,10 +124,18 @@ int brbd_model_create(const brbd_model_desc* desc, int device, brbd_model** out)
 int brbd_model_canonical_form(const brbd_model_desc* desc, int32_t* jtype, double* placement,
                               double* inertia, double* post);
 int brbd_model_destroy(brbd_model* m);
+/* Per-stream buffers.  The handle keeps, per stream it has been called on, the kernels' workspace and
+ * (for BRBD_HOST / INSTANCE_MAJOR nv x nv calls) staging buffers: up to 1 GiB of batch-major copies,
+ * 256 MiB of device staging and as much pinned host memory, all alive until brbd_model_destroy.  A
+ * caller that uses many short-lived streams on a long-lived handle releases a stream's share here:
+ * the call waits for the work queued on `stream` and frees its buffers (they are re-created on the
+ * next call on that stream).  No reference counterpart. */
+int brbd_model_release_stream(brbd_model* m, void* stream);
 int brbd_model_dims(const brbd_model* m, int32_t* njoints, int32_t* nq, int32_t* nv);
 
-/* Bytes of device workspace the kernels spill to for a batch of B instances
- * (reported separately from algorithmic I/O in the roofline). */
+/* Bytes of device workspace the table-driven kernels spill to for a batch of B instances
+ * (reported separately from algorithmic I/O in the roofline); -1 for an algorithm without a
+ * workspace of its own (BRBD_ALGO_ABA_DERIV_PRODUCTS). */
 int64_t brbd_workspace_bytes(const brbd_model* m, int algo, int64_t B);
 enum brbd_algo { BRBD_ALGO_RNEA = 0, BRBD_ALGO_ABA = 1, BRBD_ALGO_FK_JAC = 2, BRBD_ALGO_RNEA_DERIV = 3,
                  BRBD_ALGO_MINVERSE = 4, BRBD_ALGO_ABA_DERIV_PRODUCTS = 5 };
@@ -237,7 +245,10 @@ int brbd_integrate(brbd_model* m, int64_t B, const double* q, int64_t ldq, const
 /* computeMinverse(model, data, q) per instance (algorithm/aba.hxx:841-877): Minv is (nv * nv) x B,
  * per instance column-major nv x nv; like data.Minv in the reference only the UPPER triangle (and the
  * diagonal blocks of multi-dof joints) is computed, the strictly lower part is written as zero.
- * Needs depth-first joint numbering (BRBD_ERR_UNSUPPORTED otherwise).  Models with compiled
+ * Needs depth-first joint numbering: every subtree a contiguous index range, which is what the
+ * reference assumes implicitly through data.nvSubtree (multibody/data.hxx:205-230) and what
+ * Model::addJoint produces for trees built limb by limb; BRBD_ERR_UNSUPPORTED otherwise (also
+ * brbd_rnea_derivatives and brbd_aba_derivatives).  Models with compiled
  * kernels run the model-compiled computeMinverse (pinocchio_amd/codegen/minv.py) on BATCH_MAJOR
  * device matrices (INSTANCE_MAJOR ones go through batch-major copies, see brbd_rnea_derivatives). */
 int brbd_minverse(brbd_model* m, int64_t B, const double* q, int64_t ldq, double* Minv, int64_t ldminv, int layout,
@@ -317,6 +328,8 @@ int brbd_set_timing(brbd_model* m, int enabled);
  * (launch k of RNEA and launch k of ABA are timed together); an untimed launch in between breaks
  * the chain, so a timed launch never includes an untimed one.  No reference counterpart. */
 int brbd_set_timing_period(brbd_model* m, int period);
+/* (every enum brbd_algo value is timed, compiled and table-driven kernels alike; brbd_integrate and
+ * brbd_joint_jacobian have no enum value and are not timed) */
 int brbd_kernel_time(brbd_model* m, int algo, int32_t* launches, double* total_ms);
 
 #ifdef __cplusplus

@@ -33,7 +33,7 @@ WORLD, LOCAL, LOCAL_WORLD_ALIGNED = 0, 1, 2
 # every extern "C" symbol of include/brbd.h (checked by tests/test_capi_host.py)
 SYMBOLS = (
     "brbd_last_error", "brbd_version", "brbd_device_count",
-    "brbd_model_create", "brbd_model_destroy", "brbd_model_dims", "brbd_workspace_bytes",
+    "brbd_model_create", "brbd_model_destroy", "brbd_model_release_stream", "brbd_model_dims", "brbd_workspace_bytes",
     "brbd_rnea", "brbd_aba", "brbd_rnea_fext", "brbd_aba_fext", "brbd_fk_jacobians", "brbd_joint_jacobian", "brbd_rnea_derivatives",
     "brbd_transpose_to_batch_major", "brbd_transpose_to_instance_major",
     "brbd_set_timing", "brbd_set_timing_period", "brbd_kernel_time", "brbd_model_compiled_kernels", "brbd_model_use_compiled", "brbd_model_outputs_prezeroed", "brbd_model_canonical_form",
@@ -115,6 +115,8 @@ def lib():
     L.brbd_model_create.argtypes = [ctypes.POINTER(brbd_model_desc), ci, ctypes.POINTER(vp)]
     L.brbd_model_destroy.restype = ci
     L.brbd_model_destroy.argtypes = [vp]
+    L.brbd_model_release_stream.restype = ci
+    L.brbd_model_release_stream.argtypes = [vp, vp]
     L.brbd_model_dims.restype = ci
     L.brbd_model_dims.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(i32)]
     L.brbd_workspace_bytes.restype = i64
@@ -221,6 +223,10 @@ class DeviceModel:
             self.close()
         except Exception:
             pass
+
+    def release_stream(self, stream=None):
+        """free the per-stream buffers the handle keeps for ``stream`` (include/brbd.h)"""
+        check(lib().brbd_model_release_stream(self.handle, stream))
 
     def workspace_bytes(self, algo: int, B: int) -> int:
         return int(lib().brbd_workspace_bytes(self.handle, algo, B))

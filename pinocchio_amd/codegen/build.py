@@ -2,10 +2,12 @@
 
     python -m pinocchio_amd.codegen.build [--out pinocchio_amd/csrc/gen] [--models a,b,...]
 
-For every registered model two variants are emitted: ``p`` (pattern: exact zeros / +-1 of the
-model's constants folded; serves models with the same tree, joint kinds and zero pattern) and
-``d`` (dense: every geometric / inertial constant generic; serves any model with the same tree
-and joint kinds).  Output per variant: ``spec_<model>_<v>.hip`` (kernel shells + registry entry)
+Variants of a registered model: ``p`` (pattern: exact zeros / +-1 of the model's constants
+folded; serves models with the same tree, joint kinds and zero pattern), ``a`` (the same with the
+armature of every 1-dof joint a run-time constant: robots with rotor inertias; shares the kernels
+the armature does not enter with ``p``) and, on request, ``d`` (dense: every geometric / inertial
+constant generic; serves any model with the same tree and joint kinds).  Gravity is a run-time
+constant in all of them.  Output per variant: ``spec_<model>_<v>.hip`` (kernel shells + registry entry)
 and the bodies ``<model>_<v>_<algo>.inc``; plus ``registry.inc`` listing all entries.
 pinocchio_amd/csrc/Makefile compiles each ``.hip`` as its own translation unit.
 """
@@ -36,13 +38,17 @@ ALGO_ORDER = ["rnea", "aba", "fkjac", "deriv", "minv", "prod"]
 WANTS = {"rnea": [1, 33], "aba": [1, 33], "fkjac": [1, 2, 3], "deriv": [31, 15], "minv": [17, 19], "prod": [3]}
 # Kernel layouts per algorithm: 0 INSTANCE_MAJOR per lane, 1 BATCH_MAJOR, 2 INSTANCE_MAJOR staged through
 # LDS (csrc/brbd_spec.hpp: SpecIn / SpecOut; inputs q, v, a | tau and the one output are small
-# enough to transpose in one go).  Staging mode of the inputs: 0 = registers (the RNEA kernels use
-# ~150 of 512 VGPRs), 1 = the wave's global staging rows (ABA has no registers to spare).
+# enough to transpose in one go).  Staging mode of the inputs: 0 = registers, 1 = the wave's global
+# staging rows.  Round 2's world-frame ABA had no registers to spare and used mode 1 (106 rows out to
+# global memory and back: 2.6x the algorithmic traffic); the local-frame ABA stages into registers like
+# RNEA: the staged values die as the walk consumes them while the hand-off records are born, and the
+# 20 doubles per lane hipcc cannot place go to scratch (humanoid, MI355X: 2.05e9 -> 2.49e9 evals/s in
+# the reference's layout; lower park budgets instead of the spills: 2.39e9).
 # (minv: BATCH_MAJOR only -- INSTANCE_MAJOR calls of the nv x nv outputs run on batch-major copies anyway)
 # fkjac: layout 2 for models whose outputs are emitted in increasing element order (fkjac.monotone):
 # both outputs are streamed out in chunks of 64 rows
 LAYOUTS = {"rnea": (0, 1, 2), "aba": (0, 1, 2), "fkjac": (0, 1, 2), "deriv": (0, 1), "minv": (1,), "prod": (1,)}
-STAGE_MODE = {"rnea": 0, "aba": 1, "fkjac": 0, "deriv": 0, "minv": 0, "prod": 0}
+STAGE_MODE = {"rnea": 0, "aba": 0, "fkjac": 0, "deriv": 0, "minv": 0, "prod": 0}
 STAGED_WANTS = [1]  # (the external-force variants read 6 * njoints more rows per lane anyway: not staged)
 
 
@@ -52,6 +58,16 @@ def _layouts(algo: str, model) -> tuple:
         if not fkjac.monotone(joints.ModelView(model)):
             return (0, 1)
     return LAYOUTS[algo]
+
+
+def _stage_mode(algo: str, model) -> int:
+    """Register staging of the layout-2 ABA kernel only while the staged tile (nq + 2 nv doubles per
+    lane) fits next to the kernel's register parks: simple_humanoid (106) spills 20 doubles per lane
+    and no SGPR; talos_like (115) spills 57 AND 12 SGPRs, the combination that is never shipped
+    (codegen/usage.py) -- such models keep the global staging rows."""
+    if algo == "aba" and STAGE_MODE[algo] == 0 and model.nq + 2 * model.nv > 108:
+        return 1
+    return STAGE_MODE[algo]
 
 
 def _staged_wants(algo: str):
@@ -87,7 +103,7 @@ def _emit_algo(args):
     (.kern.inc) and one translation unit per boundary layout and output mask that instantiates it."""
     out_dir, name, variant, algo = args
     model = _model(name)
-    mv = joints.ModelView(model, dense=(variant == "d"))
+    mv = joints.ModelView(model, dense=(variant == "d"), arm_generic=(variant == "a"))
     ident = "%s_%s" % (name, variant)
     k = C.build_kernel(mv, algo)
     nq, nv = model.nq, model.nv
@@ -98,7 +114,8 @@ def _emit_algo(args):
     rows2 = 12 * model.njoints if algo == "fkjac" else 0          # second output, when it is streamed too
     stream = 1 if algo == "fkjac" else 0                          # outputs leave in chunks of 64 rows
     stage_pairs = (max(rows[:3] + ((64,) if stream else rows[3:])) + 1) // 2
-    stage_rows = (nq + 2 * nv) if (staged and STAGE_MODE[algo] == 1) else 0
+    stage_mode = _stage_mode(algo, model)
+    stage_rows = (nq + 2 * nv) if (staged and stage_mode == 1) else 0
     body = "%s_%s.inc" % (ident, algo)
     _write(os.path.join(out_dir, body), k.text)
     kern = "%s_%s.kern.inc" % (ident, algo)
@@ -112,7 +129,7 @@ def _emit_algo(args):
                 2 if algo in ("rnea", "aba") else 0),
             "  // rows of q, v, the third input and the first output; staging of the layout-2 kernels",
             "  constexpr int SPEC_NQ = %d, SPEC_NV = %d, SPEC_NX = %d, SPEC_NO = %d, SPEC_STAGE_MODE = %d, SPEC_GLB = %d;" % (
-                rows + (STAGE_MODE[algo], k.glb)),
+                rows + (stage_mode, k.glb)),
             ] + (["  constexpr int SPEC_NO2 = %d, SPEC_OUT_STREAM = %d;  // (shadow the defaults of brbd_spec.hpp)" % (rows2, stream)]
                  if stream else []) + [
             "  BRBD_SPEC_PROLOGUE(LAYOUT == 2 ? %d : %d)" % (max(k.lds // 2, stage_pairs), k.lds // 2),
@@ -145,24 +162,39 @@ def _emit_algo(args):
     return algo, gather, len(k.const_list), k.lds, k.glb, stage_rows, layouts
 
 
+# the armature enters these algorithms only; the "a" variant (armature of 1-dof joints generic) shares
+# the kernels of the others with the "p" variant of the same model
+ARMATURE_ALGOS = ("rnea", "aba", "deriv", "minv")
+
+
 def emit_variant(out_dir: str, name: str, variant: str, pool=None) -> str:
     """The registry translation unit of one model variant (kernel declarations, gather lists of the
     packed constant tables, SpecEntry); the kernels themselves are compiled in TUs of their own."""
-    mv = joints.ModelView(_model(name), dense=(variant == "d"))
+    mv = joints.ModelView(_model(name), dense=(variant == "d"), arm_generic=(variant == "a"))
     ident = "%s_%s" % (name, variant)
-    jobs = [(out_dir, name, variant, algo) for algo in ALGO_ORDER]
+
+    def owner(algo):  # variant whose kernels serve this algorithm
+        return "p" if (variant == "a" and algo not in ARMATURE_ALGOS) else variant
+
+    jobs = [(out_dir, name, owner(algo), algo) for algo in ALGO_ORDER]
     results = pool.map(_emit_algo, jobs) if pool is not None else [_emit_algo(j) for j in jobs]
-    ns = "spec_%s::" % ident
     lines = [
         "// GENERATED by pinocchio_amd/codegen/build.py -- do not edit.",
         '#include "../brbd_spec.hpp"',
         "namespace brbd {",
-        "namespace spec_%s {" % ident,
     ]
+    for v in sorted({owner(a) for a in ALGO_ORDER}):
+        lines.append("namespace spec_%s_%s {" % (name, v))
+        for algo in ALGO_ORDER:
+            if owner(algo) == v:
+                lines.append("template <int LAYOUT, int WANT> __global__ void k_%s(const KArgs A);  // spec_%s_%s_%s_<layout>_<want>.hip"
+                             % (algo, name, v, algo))
+        lines.append("}  // namespace spec_%s_%s" % (name, v))
+    lines.append("namespace spec_%s {" % ident)
     entries = []
     for algo, gather, nconst, lds, glb, stage_rows, layouts in results:
+        ns = "spec_%s_%s::" % (name, owner(algo))
         lines += [
-            "template <int LAYOUT, int WANT> __global__ void k_%s(const KArgs A);  // spec_%s_%s_<layout>_<want>.hip" % (algo, ident, algo),
             "static const int32_t gather_%s[] = {%s};" % (algo, gather),
         ]
         rows = []
@@ -176,7 +208,7 @@ def emit_variant(out_dir: str, name: str, variant: str, pool=None) -> str:
                       for w in WANTS[algo]]
                 fn += ["nullptr"] * (4 - len(fn))
             rows.append("{" + ", ".join(fn) + "}")
-        entries.append("{{%s}, %sgather_%s, %d, %d, %d, %d}" % (", ".join(rows), ns, algo, nconst, lds, glb, stage_rows))
+        entries.append("{{%s}, spec_%s::gather_%s, %d, %d, %d, %d}" % (", ".join(rows), ident, algo, nconst, lds, glb, stage_rows))
     lines += [
         "}  // namespace spec_%s" % ident,
         "// host pass only: the table holds the kernels' host-side handles; their device code lives in",
@@ -197,14 +229,17 @@ def main(argv=None):
     here = os.path.dirname(os.path.abspath(__file__))
     ap.add_argument("--out", default=os.path.join(here, "..", "csrc", "gen"))
     ap.add_argument("--models", default=",".join(REGISTERED))
-    ap.add_argument("--variants", default=os.environ.get("BRBD_SPEC_VARIANTS", "p"))
+    ap.add_argument("--variants", default=os.environ.get("BRBD_SPEC_VARIANTS", "p,a"))
     a = ap.parse_args(argv)
     os.makedirs(a.out, exist_ok=True)
     idents = []
     import multiprocessing
     with multiprocessing.Pool(min(8, os.cpu_count() or 1)) as pool:
+        variants = [v for v in a.variants.split(",") if v]
+        if "a" in variants and "p" not in variants:
+            variants.insert(0, "p")  # (the "a" variant borrows the armature-free kernels of "p")
         for name in [m for m in a.models.split(",") if m]:
-            for v in a.variants.split(","):
+            for v in variants:
                 idents.append(emit_variant(a.out, name, v, pool))
                 print("generated", idents[-1], file=sys.stderr)
     reg = "// GENERATED by pinocchio_amd/codegen/build.py -- do not edit.\nnamespace brbd {\n"

@@ -21,10 +21,14 @@ RUB = (M.JOINT_RUBX, M.JOINT_RUBY, M.JOINT_RUBZ)
 class ModelView:
     """Numeric tables of one model + constant access with folding."""
 
-    def __init__(self, model: M.Model, dense: bool = False):
+    def __init__(self, model: M.Model, dense: bool = False, arm_generic: bool = False):
+        """``dense``: every geometric / inertial constant generic (any model with this tree);
+        ``arm_generic``: the armature of 1-dof joints generic (rotor inertias, aba.hxx:178-179,
+        rnea.hxx:158: run-time constants instead of part of the pattern).  Gravity is always generic."""
         self.model = model
         self.t = model.tables()
         self.dense = dense
+        self.arm_generic = arm_generic or dense
         self.n = model.njoints
         self.parents = [int(p) for p in self.t["parents"]]
         self.jtype = [int(x) for x in self.t["jtype"]]
@@ -33,6 +37,19 @@ class ModelView:
         self.children: List[List[int]] = [[] for _ in range(self.n)]
         for i in range(1, self.n):
             self.children[self.parents[i]].append(i)
+        self.dof_nv = {}  # dof index -> nv of the joint that owns it
+        for i in range(1, self.n):
+            for k in range(self.nv(i)):
+                self.dof_nv[self.idx_v[i] + k] = self.nv(i)
+
+    def generic(self, ident) -> bool:
+        """Is this constant a table entry whatever its value?"""
+        _, field, k = ident
+        if field == "g":
+            return True
+        if field == "arm":  # (multi-dof joints keep their pattern: a free-flyer without armature is solved directly)
+            return self.arm_generic and self.dof_nv.get(k, 0) == 1
+        return self.dense
 
     def nv(self, i: int) -> int:
         return M.JOINT_NV[self.jtype[i]]
@@ -61,8 +78,7 @@ class ModelView:
 
     def c(self, e: Emitter, i: int, field: str, k: int = 0) -> V:
         ident = (i, field, k)
-        # armature and gravity always fold on their exact pattern, dense kernels included
-        return e.const(self.value(ident), ident, self.dense and field not in ("arm", "g"))
+        return e.const(self.value(ident), ident, self.generic(ident))
 
     def placement(self, e: Emitter, i: int):
         R = [[self.c(e, i, "R", 3 * r + c) for c in range(3)] for r in range(3)]
@@ -77,17 +93,15 @@ class ModelView:
 
     def signature(self) -> str:
         """What a model must share with the one this kernel was generated for: the tree, the joint
-        kinds, the rows of q / v each joint owns (the bodies hard-code them) and (unless dense)
-        which constants are exactly 0 / +1 / -1."""
+        kinds, the rows of q / v each joint owns (the bodies hard-code them) and, for every constant
+        that is not generic in this variant, whether it is exactly 0 / +1 / -1."""
         head = "n%d;p%s;j%s;q%s;v%s;" % (self.n, ",".join(map(str, self.parents[1:])), ",".join(map(str, self.jtype[1:])),
                                          ",".join(map(str, self.idx_q[1:])), ",".join(map(str, self.idx_v[1:])))
         pat = []
         for ident in all_const_idents(self):
             x = self.value(ident)
             ch = "0" if x == 0.0 else ("1" if x == 1.0 else ("m" if x == -1.0 else "g"))
-            if self.dense and ident[1] not in ("arm", "g"):
-                ch = "g"
-            pat.append(ch)
+            pat.append("g" if self.generic(ident) else ch)
         return head + "".join(pat)
 
 

@@ -98,10 +98,12 @@ struct brbd_model {
   unsigned long long* d_oob = nullptr;  // checking build: out-of-range access counter of the compiled kernels
   double* scratch = nullptr;  // this device's copy of the file-scope scratch array (brbd_aba_noalloc)
   // per-algorithm launch geometry (waves resident on the device)
-  int max_waves[6] = {0, 0, 0, 0, 0, 0};
-  int max_waves_spec[6] = {0, 0, 0, 0, 0, 0};
-  int max_waves_jjac = 0;
-  int max_waves_f4[4] = {0, 0, 0, 0};  // minverse, integrate, aba-derivative products (nv <= 24, nv <= 48)
+  // (resolved on first use; atomics: two host threads may drive two streams of one handle, both
+  // would store the same value)
+  std::atomic<int> max_waves[6] = {};
+  std::atomic<int> max_waves_spec[6] = {};
+  std::atomic<int> max_waves_jjac{0};
+  std::atomic<int> max_waves_f4[4] = {};  // minverse, integrate, aba-derivative products (nv <= 24, nv <= 48)
   std::map<int, std::pair<Op*, int>> chains;  // brbd_joint_jacobian: support chain of a joint (device)
   // model-compiled kernels (brbd_spec.hpp), when the model's signature is registered
   const SpecEntry* spec = nullptr;
@@ -109,7 +111,7 @@ struct brbd_model {
   bool prezeroed = false;  // brbd_model_outputs_prezeroed: derivative kernels skip structural zeros
   bool use_spec = true;  // BRBD_DISABLE_COMPILED=1 or brbd_model_use_compiled(m, 0): table-driven kernels
   bool use_lds = true;
-  bool warned_4g = false;
+  std::atomic<bool> warned_4g{false};
   int timing = 0;  // 0 off, 1 two events per launch, 2 chained (one event per launch)
   int timing_period = 1;            // brbd_set_timing_period: every period-th launch of an algorithm is timed
   uint64_t timing_count[6] = {0, 0, 0, 0, 0, 0};
@@ -140,7 +142,10 @@ double model_constant(const FlatModel& F, int joint, int field, int index) {
     default: return F.gravity[index];
   }
 }
-std::string model_signature(const FlatModel& F, bool dense) {
+// mode 0: the exact pattern ("<name>_p"); 1: armature of 1-dof joints generic ("<name>_a": rotor
+// inertias are run-time constants); 2: geometry and inertias generic too ("<name>_d").  Gravity is
+// generic in every variant; the armature of multi-dof joints always keeps its pattern.
+std::string model_signature(const FlatModel& F, int mode) {
   std::string s = "n" + std::to_string(F.njoints) + ";p";
   for (int i = 1; i < F.njoints; ++i) s += (i > 1 ? "," : "") + std::to_string(F.tab_desc[i].parent);
   s += ";j";
@@ -151,20 +156,21 @@ std::string model_signature(const FlatModel& F, bool dense) {
   s += ";v";
   for (int i = 1; i < F.njoints; ++i) s += (i > 1 ? "," : "") + std::to_string(F.tab_desc[i].idx_v);
   s += ";";
-  auto put = [&](double x, bool keep) {
+  auto put = [&](double x, bool generic) {
     char c = x == 0.0 ? '0' : (x == 1.0 ? '1' : (x == -1.0 ? 'm' : 'g'));
-    s += (dense && !keep) ? 'g' : c;
+    s += generic ? 'g' : c;
   };
+  const bool dense = mode == 2;
   for (int k = 0; k < 3; ++k) put(F.gravity[k], true);
   for (int i = 1; i < F.njoints; ++i) {
     const JointConst& jc = F.tab_desc[i];
-    for (int k = 0; k < 9; ++k) put(jc.R[k], false);
-    for (int k = 0; k < 3; ++k) put(jc.t[k], false);
-    put(jc.m, false);
-    for (int k = 0; k < 3; ++k) put(jc.c[k], false);
-    for (int k = 0; k < 6; ++k) put(jc.I[k], false);
-    for (int k = 0; k < 3; ++k) put(jc.axis[k], false);
-    for (int k = 0; k < jc.nvj; ++k) put(jc.arm[k], true);
+    for (int k = 0; k < 9; ++k) put(jc.R[k], dense);
+    for (int k = 0; k < 3; ++k) put(jc.t[k], dense);
+    put(jc.m, dense);
+    for (int k = 0; k < 3; ++k) put(jc.c[k], dense);
+    for (int k = 0; k < 6; ++k) put(jc.I[k], dense);
+    for (int k = 0; k < 3; ++k) put(jc.axis[k], dense);
+    for (int k = 0; k < jc.nvj; ++k) put(jc.arm[k], mode >= 1 && jc.nvj == 1);
   }
   return s;
 }
@@ -312,9 +318,11 @@ struct Timer {
     if (!timing_sampled(m, algo)) return BRBD_OK;
     // chained timing (brbd_set_timing(m, 2)): the event that closed the previous launch of this
     // handle on this stream opens this one: one event per launch instead of two
-    if (m->timing >= 2 && m->last_stop && m->last_stream == s) {
-      t.start = m->last_stop;
-    } else {
+    {
+      std::lock_guard<std::mutex> g(m->mu);  // (Timer::end and timing_sampled write these under the lock)
+      if (m->timing >= 2 && m->last_stop && m->last_stream == s) t.start = m->last_stop;
+    }
+    if (!t.start) {
       t.start = std::make_shared<Ev>();
       HIP_TRY(hipEventCreate(&t.start->e));
       HIP_TRY(hipEventRecord(t.start->e, s));
@@ -381,8 +389,7 @@ int launch_algo(brbd_model* m, int algo, KArgs& A, int layout, hipStream_t strea
       if (span >= 4294967295.0) {
         // 32-bit byte offsets: a matrix of 4 GiB or more runs on the (slower) table-driven kernels.
         // Loud, once per handle: callers should split the batch by columns instead.
-        if (!m->warned_4g) {
-          m->warned_4g = true;
+        if (!m->warned_4g.exchange(true)) {
           fprintf(stderr, "brbd: a boundary matrix of this call spans >= 4 GiB: the model-compiled kernels "
                           "(32-bit offsets) do not apply, using the table-driven kernels; split the batch by "
                           "columns to stay on the compiled ones\n");
@@ -408,14 +415,14 @@ int launch_algo(brbd_model* m, int algo, KArgs& A, int layout, hipStream_t strea
   const bool stat = sk != nullptr;
   SpecFn sfn = stat ? sk->fn[klayout][variant] : nullptr;
   const int stage = stat && klayout == 2 ? sk->stage_doubles : 0;
-  int& mw = stat ? m->max_waves_spec[algo] : m->max_waves[algo];
+  std::atomic<int>& mw_cache = stat ? m->max_waves_spec[algo] : m->max_waves[algo];
+  int mw = mw_cache.load(std::memory_order_relaxed);
   if (mw == 0) {
-    int w = 0;
-    if (stat) w = resident_waves(m, sfn, WAVE);
-    else if (algo == BRBD_ALGO_RNEA) w = resident_waves(m, rnea_kernel<1>, WAVE);
-    else if (algo == BRBD_ALGO_ABA) w = resident_waves(m, aba_kernel<1>, WAVE);
-    else w = resident_waves(m, fkjac_kernel<1>, WAVE);
-    mw = w;  // register/LDS-limited resident waves on the whole device
+    if (stat) mw = resident_waves(m, sfn, WAVE);
+    else if (algo == BRBD_ALGO_RNEA) mw = resident_waves(m, rnea_kernel<1>, WAVE);
+    else if (algo == BRBD_ALGO_ABA) mw = resident_waves(m, aba_kernel<1>, WAVE);
+    else mw = resident_waves(m, fkjac_kernel<1>, WAVE);
+    mw_cache.store(mw, std::memory_order_relaxed);  // register/LDS-limited resident waves on the whole device
   }
   // LDS part of the live-state stack (generic RNEA / ABA): as many slots as fit without lowering
   // the number of waves per CU below what this launch can use.
@@ -672,16 +679,17 @@ int brbd_model_create(const brbd_model_desc* desc, int device, brbd_model** out)
   if (e == hipSuccess)
     e = upload((void**)&m->d_nvsub, m->flat.nv_subtree.data(), m->flat.nv_subtree.size() * sizeof(int));
   if (e == hipSuccess) {
-    // model-compiled kernels: exact zero pattern first, then the dense kernels of the same tree;
-    // the kernels built into the library first, then those of plugins loaded at run time
+    // model-compiled kernels: exact zero pattern first, then the same pattern with run-time
+    // armature, then the dense kernels of the same tree; the kernels built into the library first,
+    // then those of plugins loaded at run time
     load_plugins_from_env();
-    const std::string exact = model_signature(m->flat, false), dense = model_signature(m->flat, true);
+    const std::string sig[3] = {model_signature(m->flat, 0), model_signature(m->flat, 1), model_signature(m->flat, 2)};
     std::lock_guard<std::mutex> g(g_plugin_mu);
-    for (int pass = 0; pass < 2 && !m->spec; ++pass) {
+    for (int pass = 0; pass < 3 && !m->spec; ++pass) {
       for (int k = 0; k < spec_entry_count && !m->spec; ++k)
-        if ((pass == 0 ? exact : dense) == spec_entries[k]->signature) m->spec = spec_entries[k];
+        if (sig[pass] == spec_entries[k]->signature) m->spec = spec_entries[k];
       for (size_t k = 0; k < g_plugin_entries.size() && !m->spec; ++k)
-        if ((pass == 0 ? exact : dense) == g_plugin_entries[k]->signature) m->spec = g_plugin_entries[k];
+        if (sig[pass] == g_plugin_entries[k]->signature) m->spec = g_plugin_entries[k];
     }
     for (int a = 0; m->spec && a < 6 && e == hipSuccess; ++a) {
       const std::vector<double> ct = pack_constants(m->flat, m->spec->algo[a]);
@@ -706,7 +714,7 @@ int brbd_model_create(const brbd_model_desc* desc, int device, brbd_model** out)
     brbd_model_destroy(m);
     return fail(BRBD_ERR_RUNTIME, msg);
   }
-  m->max_waves[BRBD_ALGO_ABA] = resident_waves(m, aba_kernel<1>, WAVE);
+  m->max_waves[BRBD_ALGO_ABA].store(resident_waves(m, aba_kernel<1>, WAVE));
   *out = m;
   return BRBD_OK;
 }
@@ -730,6 +738,28 @@ int brbd_model_destroy(brbd_model* m) {
   return BRBD_OK;
 }
 
+int brbd_model_release_stream(brbd_model* m, void* stream) {
+  if (!m) return fail(BRBD_ERR_INVALID_ARGUMENT, "model handle is NULL");
+  DevGuard dg(m->device);
+  if (!dg.ok) return fail(BRBD_ERR_RUNTIME, "hipSetDevice failed");
+  std::unique_ptr<StreamCtx> ctx;
+  {
+    std::lock_guard<std::mutex> g(m->mu);
+    auto it = m->ctxs.find((hipStream_t)stream);
+    if (it == m->ctxs.end()) return BRBD_OK;
+    ctx = std::move(it->second);
+    m->ctxs.erase(it);
+    if (m->last_stream == (hipStream_t)stream) m->last_stop.reset();
+  }
+  if (!ctx) return BRBD_OK;
+  // everything queued with these buffers must have finished before they go
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  for (int k = 0; k < 2; ++k)
+    if (ctx->pipe[k]) (void)hipStreamSynchronize(ctx->pipe[k]);
+  free_ctx(*ctx);
+  return BRBD_OK;
+}
+
 int brbd_model_dims(const brbd_model* m, int32_t* njoints, int32_t* nq, int32_t* nv) {
   if (!m) return fail(BRBD_ERR_INVALID_ARGUMENT, "model handle is NULL");
   if (njoints) *njoints = m->flat.njoints;
@@ -747,7 +777,8 @@ int64_t brbd_workspace_bytes(const brbd_model* m, int algo, int64_t B) {
     case BRBD_ALGO_ABA: per_lane = F.ws_aba(); break;
     case BRBD_ALGO_FK_JAC: per_lane = F.ws_fkjac(); break;
     case BRBD_ALGO_RNEA_DERIV: per_lane = deriv_ws_per_lane(F); break;
-    default: return -1;
+    case BRBD_ALGO_MINVERSE: per_lane = minverse_ws_per_lane(F); break;
+    default: return -1;  // (BRBD_ALGO_ABA_DERIV_PRODUCTS: no workspace of its own)
   }
   const int64_t tiles = (B + WAVE - 1) / WAVE;
   return tiles * WAVE * (int64_t)per_lane * 8;
@@ -998,6 +1029,16 @@ int host_pipeline(brbd_model* m, int64_t B, int layout, const HostMat* mats, int
     if (!ctx->ev_done[k]) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_done[k], hipEventDisableTiming));
   }
   if (!ctx->ev_in) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_in, hipEventDisableTiming));
+  // Whatever way this call ends, nothing of it may still be in flight when it returns: an error path
+  // would otherwise leave queued copies into the caller's matrices (or the pinned bounce slots the
+  // next call reuses) running after the BRBD_HOST call has reported its status.
+  struct Drain {
+    StreamCtx* c;
+    ~Drain() {
+      for (int k = 0; k < 2; ++k)
+        if (c->pipe[k]) (void)hipStreamSynchronize(c->pipe[k]);
+    }
+  } drain{ctx};
   // order the pipeline after what the caller already queued on its stream
   HIP_TRY(hipEventRecord(ctx->ev_in, user));
   for (int k = 0; k < 2; ++k) HIP_TRY(hipStreamWaitEvent(ctx->pipe[k], ctx->ev_in, 0));
@@ -1321,8 +1362,9 @@ int brbd_joint_jacobian(brbd_model* m, int64_t B, const double* q, int64_t ldq, 
     A.nops3 = nchain;
     A.rf = rf;
     A.q = dq; A.ldq = ldq_; A.out = dJ; A.ldout = ldJ_;
-    if (m->max_waves_jjac == 0) m->max_waves_jjac = resident_waves(m, jjac_kernel<1>, WAVE);
-    const int64_t grid = A.ntiles < m->max_waves_jjac ? A.ntiles : m->max_waves_jjac;
+    if (m->max_waves_jjac.load() == 0) m->max_waves_jjac.store(resident_waves(m, jjac_kernel<1>, WAVE));
+    const int64_t mwj = m->max_waves_jjac.load();
+    const int64_t grid = A.ntiles < mwj ? A.ntiles : mwj;
     const dim3 g((unsigned)grid), b(WAVE);
     if (layout == BRBD_BATCH_MAJOR) hipLaunchKernelGGL(jjac_kernel<1>, g, b, 0, st, A);
     else hipLaunchKernelGGL(jjac_kernel<0>, g, b, 0, st, A);
@@ -1362,9 +1404,10 @@ int deriv_device(brbd_model* m, int64_t Bc, const double* const* in, const int64
   D.q = in[0]; D.ldq = ldi[0]; D.v = in[1]; D.ldv = ldi[1]; D.a = in[2]; D.lda = ldi[2];
   D.dq = out[0]; D.lddq = ldo[0]; D.dv = out[1]; D.lddv = ldo[1]; D.da = out[2]; D.ldda = ldo[2];
   D.tau = out[3]; D.ldtau = ldo[3];
-  if (m->max_waves[BRBD_ALGO_RNEA_DERIV] == 0)
-    m->max_waves[BRBD_ALGO_RNEA_DERIV] = resident_waves(m, rnea_deriv_kernel<1>, WAVE);
-  const int64_t grid = D.ntiles < m->max_waves[3] ? D.ntiles : m->max_waves[3];
+  if (m->max_waves[BRBD_ALGO_RNEA_DERIV].load() == 0)
+    m->max_waves[BRBD_ALGO_RNEA_DERIV].store(resident_waves(m, rnea_deriv_kernel<1>, WAVE));
+  const int64_t mwd = m->max_waves[3].load();
+  const int64_t grid = D.ntiles < mwd ? D.ntiles : mwd;
   D.ws_stride = (int64_t)deriv_ws_per_lane(F) * WAVE;
   StreamCtx* ctx = get_ctx(m, st);
   int r = ensure_buf(&ctx->d_ws, &ctx->ws_doubles, (size_t)grid * D.ws_stride, st);
@@ -1454,9 +1497,13 @@ void fill_f4(const brbd_model* m, F4Args& A, int64_t B) {
   A.ntiles = (B + WAVE - 1) / WAVE;
 }
 template <typename K>
-int f4_grid(brbd_model* m, int& cache, K kernel, int64_t ntiles) {
-  if (cache == 0) cache = resident_waves(m, kernel, WAVE);
-  return (int)(ntiles < cache ? ntiles : cache);
+int f4_grid(brbd_model* m, std::atomic<int>& cache, K kernel, int64_t ntiles) {
+  int w = cache.load(std::memory_order_relaxed);
+  if (w == 0) {
+    w = resident_waves(m, kernel, WAVE);
+    cache.store(w, std::memory_order_relaxed);
+  }
+  return (int)(ntiles < w ? ntiles : w);
 }
 int minverse_device(brbd_model* m, int64_t B, const double* q, int64_t ldq, double* Minv, int64_t ldm, int full,
                     int layout, hipStream_t st) {
@@ -1478,10 +1525,12 @@ int minverse_device(brbd_model* m, int64_t B, const double* q, int64_t ldq, doub
   int rc = ensure_buf(&ctx->d_ws, &ctx->ws_doubles, (size_t)grid * A.ws_stride, st);
   if (rc) return rc;
   A.ws = ctx->d_ws;
+  Timer tm{m, BRBD_ALGO_MINVERSE, st};
+  if ((rc = tm.begin())) return rc;
   if (layout == BRBD_BATCH_MAJOR) hipLaunchKernelGGL(minverse_kernel<1>, dim3(grid), dim3(WAVE), 0, st, A);
   else hipLaunchKernelGGL(minverse_kernel<0>, dim3(grid), dim3(WAVE), 0, st, A);
   HIP_TRY(hipGetLastError());
-  return BRBD_OK;
+  return tm.end();
 }
 }  // namespace
 }  // extern "C++"
@@ -1596,6 +1645,8 @@ int brbd_aba_derivatives(brbd_model* m, int64_t B, const double* q, int64_t ldq,
     // (4 columns of both factors in registers for nv <= 24, 2 for nv <= 48: about 200 doubles)
     const int grid = F.nv <= 24 ? f4_grid(m, m->max_waves_f4[2], aba_deriv_product_kernel<1, 24, 4>, A.ntiles)
                                 : f4_grid(m, m->max_waves_f4[3], aba_deriv_product_kernel<1, 48, 2>, A.ntiles);
+    Timer tm{m, BRBD_ALGO_ABA_DERIV_PRODUCTS, st};
+    if ((r = tm.begin())) return r;
     if (layout == BRBD_BATCH_MAJOR) {
       if (F.nv <= 24) hipLaunchKernelGGL((aba_deriv_product_kernel<1, 24, 4>), dim3(grid), dim3(WAVE), 0, st, A);
       else hipLaunchKernelGGL((aba_deriv_product_kernel<1, 48, 2>), dim3(grid), dim3(WAVE), 0, st, A);
@@ -1604,7 +1655,7 @@ int brbd_aba_derivatives(brbd_model* m, int64_t B, const double* q, int64_t ldq,
       else hipLaunchKernelGGL((aba_deriv_product_kernel<0, 48, 2>), dim3(grid), dim3(WAVE), 0, st, A);
     }
     HIP_TRY(hipGetLastError());
-    return BRBD_OK;
+    return tm.end();
   };
   if (memspace == BRBD_DEVICE && layout == BRBD_INSTANCE_MAJOR && B >= 4096 && via_bm_enabled()) {
     // every stage is output-bound: the whole composition runs on batch-major copies

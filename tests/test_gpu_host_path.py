@@ -219,3 +219,30 @@ def test_one_process_several_devices_column_split(order):
     with pytest.raises(capi.BrbdInvalidArgument):
         parallel.rneaInParallelOnDevices(1, pool, qq, vv, aa, devices=[])
     pool.release()
+
+
+def test_release_stream_frees_and_recreates_the_per_stream_buffers():
+    """brbd_model_release_stream (include/brbd.h): a stream's workspace / staging share goes away and
+    comes back on the next call; results unchanged.  And the table-driven computeMinverse is timed
+    like every other enum brbd_algo value (brbd_kernel_time)."""
+    import torch
+    model = S.quadruped()
+    pool = parallel.ModelPool(model, 1)
+    dm = pool.device_model(0)
+    O = oracle.Oracle(model)
+    q, v, a = inputs(model, 5000, 9)
+    tau1 = parallel.rneaInParallel(1, pool, q, v, a)   # host memory: staging buffers of the NULL stream
+    dm.release_stream(None)
+    dm.release_stream(None)                            # (nothing left: a no-op)
+    dm.release_stream(ctypes.c_void_p(12345))          # (a stream the handle never saw)
+    tau2 = parallel.rneaInParallel(1, pool, q, v, a)
+    assert np.array_equal(tau1, tau2)
+    assert rel_err_cols(tau1, O.rnea(q, v, a)).max() < 1e-12
+    dm.use_compiled(False)
+    dm.set_timing(True)
+    parallel.computeMinverse(pool, torch.from_numpy(np.ascontiguousarray(q)).cuda())
+    n, ms = dm.kernel_time(capi.ALGO_MINVERSE)
+    dm.set_timing(False)
+    assert n == 1 and ms > 0
+    assert dm.workspace_bytes(capi.ALGO_MINVERSE, 64) > 0
+    pool.release()

@@ -516,16 +516,28 @@ def test_unregistered_model_uses_table_driven_kernels():
 
 
 def test_compiled_kernels_armature_and_gravity_change_selection():
-    """Armature and gravity patterns are part of the signature: a registered tree with armature
-    falls back to the table-driven kernels and still matches the oracle."""
-    model = S.quadruped()
-    model.armature = np.linspace(0.05, 0.2, model.nv)
-    pool = parallel.ModelPool(model, 1)
-    assert pool.device_model(0).compiled_kernels() == ""
-    _check_all(pool, model, oracle.Oracle(model))
-    pool.release()
+    """Armature (rotor inertias: aba.hxx:178-179, rnea.hxx:158; the reference's own tests set it,
+    unittest/rnea.cpp:198-206) and gravity are RUN-TIME constants of the compiled kernels: a
+    registered tree with armature on its 1-dof joints keeps compiled kernels (the "_a" variant), one
+    with another gravity vector keeps the pattern kernels; both match the oracle on every algorithm."""
+    for name in ("quadruped", "simple_humanoid"):
+        model = S.build(name)
+        arm = np.linspace(0.05, 0.2, model.nv)
+        arm[:6] = 0.0  # (free-flyer: no rotor)
+        model.armature = arm
+        pool = parallel.ModelPool(model, 1)
+        assert pool.device_model(0).compiled_kernels() == name + "_a"
+        _check_all(pool, model, oracle.Oracle(model))
+        pool.release()
     model = S.quadruped()
     model.gravity = np.array([0.3, -0.2, -9.0])
+    pool = parallel.ModelPool(model, 1)
+    assert pool.device_model(0).compiled_kernels() == "quadruped_p"
+    _check_all(pool, model, oracle.Oracle(model))
+    pool.release()
+    # armature on the free-flyer itself is not a pattern any built-in kernel was generated for
+    model = S.quadruped()
+    model.armature = np.full(model.nv, 0.1)
     pool = parallel.ModelPool(model, 1)
     assert pool.device_model(0).compiled_kernels() == ""
     _check_all(pool, model, oracle.Oracle(model))

@@ -13,4 +13,5 @@ find gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {}
 head -12 gpurun_out/${TAG}_kernel_stats.csv | cut -c1-200
 tools/pmc_passes.sh $TAG || exit 1
 python3 tools/pmc_summary.py $TAG > gpurun_out/${TAG}_pmc_summary.json && python3 tools/pmc_digest.py gpurun_out/${TAG}_pmc_summary.json > gpurun_out/${TAG}_pmc_digest.txt
+python3 tools/pmc_traffic.py gpurun_out/${TAG}_pmc_summary.json gpurun_out/${TAG}_pmc_traffic.json > /dev/null
 cat gpurun_out/${TAG}_pmc_digest.txt | head -60

@@ -138,7 +138,7 @@ int brbd_model_dims(const brbd_model* m, int32_t* njoints, int32_t* nq, int32_t*
  * workspace of its own (BRBD_ALGO_ABA_DERIV_PRODUCTS). */
 int64_t brbd_workspace_bytes(const brbd_model* m, int algo, int64_t B);
 enum brbd_algo { BRBD_ALGO_RNEA = 0, BRBD_ALGO_ABA = 1, BRBD_ALGO_FK_JAC = 2, BRBD_ALGO_RNEA_DERIV = 3,
-                 BRBD_ALGO_MINVERSE = 4, BRBD_ALGO_ABA_DERIV_PRODUCTS = 5 };
+                 BRBD_ALGO_MINVERSE = 4, BRBD_ALGO_ABA_DERIV_PRODUCTS = 5, BRBD_ALGO_JOINT_JAC = 6 };
 
 /* tau = RNEA(q, v, a) for B instances.
  * Replaces the loop body of rneaInParallel (algorithm/parallel/rnea.hpp:74-82)
@@ -214,7 +214,9 @@ int brbd_fk_jacobians(brbd_model* m, int64_t B, const double* q, int64_t ldq, do
  * (algorithm/jacobian.hxx:38-95, 175-283, 315-326): J is (6 * nv) x B, per instance a column-major
  * 6 x nv matrix; the columns of the joint's support (the joint and its ancestors) hold the joint
  * Jacobian expressed in rf (pinocchio::ReferenceFrame: 0 WORLD, 1 LOCAL, 2 LOCAL_WORLD_ALIGNED),
- * every other column is written as zero (the reference leaves them to the caller's setZero()). */
+ * every other column is written as zero (the reference leaves them to the caller's setZero()).
+ * Models with compiled kernels and at most 64 joints run the model-compiled kernel
+ * (pinocchio_amd/codegen/jjac.py: one kernel per model and frame, the joint a run-time argument). */
 int brbd_joint_jacobian(brbd_model* m, int64_t B, const double* q, int64_t ldq, int joint, int rf,
                         double* J, int64_t ldJ, int layout, int memspace, void* stream);
 
@@ -328,8 +330,8 @@ int brbd_set_timing(brbd_model* m, int enabled);
  * (launch k of RNEA and launch k of ABA are timed together); an untimed launch in between breaks
  * the chain, so a timed launch never includes an untimed one.  No reference counterpart. */
 int brbd_set_timing_period(brbd_model* m, int period);
-/* (every enum brbd_algo value is timed, compiled and table-driven kernels alike; brbd_integrate and
- * brbd_joint_jacobian have no enum value and are not timed) */
+/* (every enum brbd_algo value is timed, compiled and table-driven kernels alike; brbd_integrate
+ * has no enum value and is not timed) */
 int brbd_kernel_time(brbd_model* m, int algo, int32_t* launches, double* total_ms);
 
 #ifdef __cplusplus

@@ -26,7 +26,7 @@ BATCH_MAJOR = 1
 HOST = 0
 DEVICE = 1
 
-ALGO_RNEA, ALGO_ABA, ALGO_FK_JAC, ALGO_RNEA_DERIV, ALGO_MINVERSE = 0, 1, 2, 3, 4
+ALGO_RNEA, ALGO_ABA, ALGO_FK_JAC, ALGO_RNEA_DERIV, ALGO_MINVERSE, ALGO_ABA_DERIV_PRODUCTS, ALGO_JOINT_JAC = 0, 1, 2, 3, 4, 5, 6
 # pinocchio::ReferenceFrame (multibody/fwd.hpp:46-54)
 WORLD, LOCAL, LOCAL_WORLD_ALIGNED = 0, 1, 2
 

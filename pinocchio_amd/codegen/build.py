@@ -28,14 +28,17 @@ from . import joints
 # until the generator feeds their constants through another path.
 REGISTERED = ["simple_humanoid", "talos_like", "quadruped", "arm7", "manipulator"]
 FIELD = {"R": 0, "t": 1, "m": 2, "c": 3, "I": 4, "arm": 5, "axis": 6, "g": 7}
-ALGO_ORDER = ["rnea", "aba", "fkjac", "deriv", "minv", "prod"]
+ALGO_ORDER = ["rnea", "aba", "fkjac", "deriv", "minv", "prod", "jjac"]
 
 
 # kernel variants (WANT masks) per algorithm; fkjac: bit 0 = J, bit 1 = oMi; deriv: all four outputs
 # compiled in (an absent one has a zero-length buffer range, so its stores are dropped by the
 # hardware), bit 4 = also write the structural zeros; rnea / aba: bit 5 = external forces
 # minv: bit 4 = write the structural zeros (always), bit 1 = symmetric fill (computeABADerivatives)
-WANTS = {"rnea": [1, 33], "aba": [1, 33], "fkjac": [1, 2, 3], "deriv": [31, 15], "minv": [17, 19], "prod": [3]}
+# jjac (getJointJacobian): bit 0 = write J, bit 1 = LOCAL, bit 2 = LOCAL_WORLD_ALIGNED (else WORLD): the
+# variant index is pinocchio::ReferenceFrame (0 WORLD, 1 LOCAL, 2 LOCAL_WORLD_ALIGNED)
+WANTS = {"rnea": [1, 33], "aba": [1, 33], "fkjac": [1, 2, 3], "deriv": [31, 15], "minv": [17, 19], "prod": [3],
+         "jjac": [1, 3, 5]}
 # Kernel layouts per algorithm: 0 INSTANCE_MAJOR per lane, 1 BATCH_MAJOR, 2 INSTANCE_MAJOR staged through
 # LDS (csrc/brbd_spec.hpp: SpecIn / SpecOut; inputs q, v, a | tau and the one output are small
 # enough to transpose in one go).  Staging mode of the inputs: 0 = registers, 1 = the wave's global
@@ -47,13 +50,14 @@ WANTS = {"rnea": [1, 33], "aba": [1, 33], "fkjac": [1, 2, 3], "deriv": [31, 15],
 # (minv: BATCH_MAJOR only -- INSTANCE_MAJOR calls of the nv x nv outputs run on batch-major copies anyway)
 # fkjac: layout 2 for models whose outputs are emitted in increasing element order (fkjac.monotone):
 # both outputs are streamed out in chunks of 64 rows
-LAYOUTS = {"rnea": (0, 1, 2), "aba": (0, 1, 2), "fkjac": (0, 1, 2), "deriv": (0, 1), "minv": (1,), "prod": (1,)}
-STAGE_MODE = {"rnea": 0, "aba": 0, "fkjac": 0, "deriv": 0, "minv": 0, "prod": 0}
+LAYOUTS = {"rnea": (0, 1, 2), "aba": (0, 1, 2), "fkjac": (0, 1, 2), "deriv": (0, 1), "minv": (1,), "prod": (1,),
+           "jjac": (0, 1, 2)}
+STAGE_MODE = {"rnea": 0, "aba": 0, "fkjac": 0, "deriv": 0, "minv": 0, "prod": 0, "jjac": 0}
 STAGED_WANTS = [1]  # (the external-force variants read 6 * njoints more rows per lane anyway: not staged)
 
 
 def _layouts(algo: str, model) -> tuple:
-    if algo == "fkjac":
+    if algo in ("fkjac", "jjac"):
         from . import fkjac
         if not fkjac.monotone(joints.ModelView(model)):
             return (0, 1)
@@ -71,7 +75,7 @@ def _stage_mode(algo: str, model) -> int:
 
 
 def _staged_wants(algo: str):
-    return WANTS[algo] if algo == "fkjac" else STAGED_WANTS
+    return WANTS[algo] if algo in ("fkjac", "jjac") else STAGED_WANTS
 for _kv in os.environ.get("BRBD_CG_STAGE_MODE", "").split(","):  # experiment hook: "aba=0"
     if "=" in _kv:
         STAGE_MODE[_kv.split("=")[0]] = int(_kv.split("=")[1])
@@ -110,9 +114,9 @@ def _emit_algo(args):
     layouts = _layouts(algo, model)
     staged = 2 in layouts
     # rows of the staged matrices: q, v, third input, first output (fkjac: q in, the Jacobian out)
-    rows = (nq, 0, 0, 6 * nv) if algo == "fkjac" else (nq, nv, nv, nv)
+    rows = (nq, 0, 0, 6 * nv) if algo in ("fkjac", "jjac") else (nq, nv, nv, nv)
     rows2 = 12 * model.njoints if algo == "fkjac" else 0          # second output, when it is streamed too
-    stream = 1 if algo == "fkjac" else 0                          # outputs leave in chunks of 64 rows
+    stream = 1 if algo in ("fkjac", "jjac") else 0                # outputs leave in chunks of 64 rows
     stage_pairs = (max(rows[:3] + ((64,) if stream else rows[3:])) + 1) // 2
     stage_mode = _stage_mode(algo, model)
     stage_rows = (nq + 2 * nv) if (staged and stage_mode == 1) else 0
@@ -204,7 +208,7 @@ def emit_variant(out_dir: str, name: str, variant: str, pool=None) -> str:
             elif algo == "fkjac":   # variant index = WANT mask
                 fn = ["nullptr"] + ["%sk_fkjac<%d, %d>" % (ns, layout, w) for w in (1, 2, 3)]
             else:                 # variant index = position in WANTS
-                fn = [("%sk_%s<%d, %d>" % (ns, algo, layout, w)) if (layout != 2 or w in STAGED_WANTS) else "nullptr"
+                fn = [("%sk_%s<%d, %d>" % (ns, algo, layout, w)) if (layout != 2 or w in _staged_wants(algo)) else "nullptr"
                       for w in WANTS[algo]]
                 fn += ["nullptr"] * (4 - len(fn))
             rows.append("{" + ", ".join(fn) + "}")

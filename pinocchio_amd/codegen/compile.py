@@ -20,17 +20,17 @@ from typing import Dict, Optional
 import numpy as np
 
 from .. import model as M
-from . import aba, aba_local, deriv, fkjac, joints, minv, prod, rnea
+from . import aba, aba_local, deriv, fkjac, jjac, joints, minv, prod, rnea
 from .emit import AHEAD, Emitter, eval_const_expr, plan_storage
 
 ALGOS = {"rnea": rnea.generate, "aba": aba.generate, "aba_local": aba_local.generate, "fkjac": fkjac.generate, "deriv": deriv.generate,
-         "minv": minv.generate, "prod": prod.generate}
+         "minv": minv.generate, "prod": prod.generate, "jjac": jjac.generate}
 
 # storage budgets (doubles per lane) of the park planner, per algorithm:
 # (registers for short-lived parks, LDS, registers for long-lived parks)
 # LDS: 160 KiB per CU, 4 resident waves of 64 lanes at one wave per SIMD -> 80 doubles per lane
 BUDGETS = {"rnea": (40, 80, 0), "aba": (48, 80, 100, 64), "aba_local": (48, 80, 100, 64), "fkjac": (36, 80, 0), "deriv": (64, 80, 32, 64),
-           "minv": (64, 80, 64, 64), "prod": (0, 0, 0)}  # (deriv: first rung of LADDER)
+           "minv": (64, 80, 64, 64), "prod": (0, 0, 0), "jjac": (0, 0, 0)}  # (deriv: first rung of LADDER)
 for _a in list(BUDGETS):  # experiment hook: BRBD_CG_ABA="64,80"
     _v = os.environ.get("BRBD_CG_" + _a.upper())
     if _v:
@@ -211,6 +211,8 @@ _CPU_SHELL = r"""
 #define PK_GLB_LD2(p, a, b) do { a = glb[2 * (p)]; b = glb[2 * (p) + 1]; } while (0)
 #define VISIT_END() do { } while (0)
 #define OPAQUE(x) do { } while (0)
+unsigned long long spec_chain = 0;  /* support chain of the joint (codegen/jjac.py), set by the test */
+#define ON_CHAIN(i) ((spec_chain >> (i)) & 1ull)
 static void one(const double* ct, const double* q, const double* v, const double* x, const double* fx,
                 double* out, double* out2, double* out3, double* out4, double* lds, double* glb) {
   (void)ct; (void)q; (void)v; (void)x; (void)fx; (void)out; (void)out2; (void)out3; (void)out4; (void)lds; (void)glb;

@@ -287,6 +287,26 @@ class Emitter:
         self.has_blocks = True
         return [V(n) for n in names]
 
+    def block(self, cond: str):
+        """``with e.block("cond"):`` -- the statements emitted inside sit in ``if (cond) { ... }``
+        (a wave-uniform or compile-time condition).  Temporaries of the block are out of scope after
+        it, so the common-subexpression table is restored on exit; loads and table constants asked for
+        inside are issued ahead of the visit as usual, i.e. unconditionally."""
+        em = self
+
+        class _Block:
+            def __enter__(self_b):
+                self_b.saved = dict(em.cse)
+                em.stmt("if (%s) {" % cond)
+                em.has_blocks = True
+
+            def __exit__(self_b, *exc):
+                em.stmt("}")
+                em.cse = self_b.saved
+                return False
+
+        return _Block()
+
     def out_filler(self, k: int, x: V, which: int = 1):
         """An output that depends on no computed value (a structural zero): text() spreads these
         evenly over the whole body, so that they drain while the arithmetic runs.  All waves of a

@@ -100,24 +100,24 @@ struct brbd_model {
   // per-algorithm launch geometry (waves resident on the device)
   // (resolved on first use; atomics: two host threads may drive two streams of one handle, both
   // would store the same value)
-  std::atomic<int> max_waves[6] = {};
-  std::atomic<int> max_waves_spec[6] = {};
+  std::atomic<int> max_waves[7] = {};
+  std::atomic<int> max_waves_spec[7] = {};
   std::atomic<int> max_waves_jjac{0};
   std::atomic<int> max_waves_f4[4] = {};  // minverse, integrate, aba-derivative products (nv <= 24, nv <= 48)
   std::map<int, std::pair<Op*, int>> chains;  // brbd_joint_jacobian: support chain of a joint (device)
   // model-compiled kernels (brbd_spec.hpp), when the model's signature is registered
   const SpecEntry* spec = nullptr;
-  double* d_ct[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // packed constant table per algorithm
+  double* d_ct[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // packed constant table per algorithm
   bool prezeroed = false;  // brbd_model_outputs_prezeroed: derivative kernels skip structural zeros
   bool use_spec = true;  // BRBD_DISABLE_COMPILED=1 or brbd_model_use_compiled(m, 0): table-driven kernels
   bool use_lds = true;
   std::atomic<bool> warned_4g{false};
   int timing = 0;  // 0 off, 1 two events per launch, 2 chained (one event per launch)
   int timing_period = 1;            // brbd_set_timing_period: every period-th launch of an algorithm is timed
-  uint64_t timing_count[6] = {0, 0, 0, 0, 0, 0};
+  uint64_t timing_count[7] = {0, 0, 0, 0, 0, 0, 0};
   std::shared_ptr<Ev> last_stop;
   hipStream_t last_stream = nullptr;
-  std::vector<TimedLaunch> timed[6];
+  std::vector<TimedLaunch> timed[7];
   std::mutex mu;
 };
 
@@ -365,6 +365,7 @@ int launch_algo(brbd_model* m, int algo, KArgs& A, int layout, hipStream_t strea
     case BRBD_ALGO_RNEA_DERIV: per_lane = 1; break;  // (only reached when a compiled kernel exists)
     case BRBD_ALGO_MINVERSE: per_lane = 1; break;    // (likewise)
     case BRBD_ALGO_ABA_DERIV_PRODUCTS: per_lane = 1; break;
+    case BRBD_ALGO_JOINT_JAC: per_lane = 1; break;
     default: return fail(BRBD_ERR_INVALID_ARGUMENT, "unknown algorithm");
   }
   // model-compiled kernel?  (BATCH_MAJOR addresses elements with 32-bit byte offsets)
@@ -374,11 +375,13 @@ int launch_algo(brbd_model* m, int algo, KArgs& A, int layout, hipStream_t strea
     if (algo == BRBD_ALGO_FK_JAC) variant = (A.out ? 1 : 0) | (A.out2 ? 2 : 0);
     else if (algo == BRBD_ALGO_RNEA_DERIV) variant = (opt < 0 ? m->prezeroed : opt != 0) ? 1 : 0;
     else if (algo == BRBD_ALGO_MINVERSE) variant = opt > 0 ? 1 : 0;
+    else if (algo == BRBD_ALGO_JOINT_JAC) variant = A.rf;  // pinocchio::ReferenceFrame
     else variant = A.fext ? 1 : 0;  // rnea / aba: kernel variant with external forces
     // buffer ranges: every matrix must span less than 4 GiB (32-bit byte offsets)
     const int64_t nn = (int64_t)F.nv * F.nv;
     const bool der = algo == BRBD_ALGO_RNEA_DERIV || algo == BRBD_ALGO_MINVERSE || algo == BRBD_ALGO_ABA_DERIV_PRODUCTS;
-    const int64_t dofs[8] = {F.nq, F.nv, F.nv, der ? nn : (algo == BRBD_ALGO_FK_JAC ? 6 * (int64_t)F.nv : F.nv),
+    const bool jac = algo == BRBD_ALGO_FK_JAC || algo == BRBD_ALGO_JOINT_JAC;
+    const int64_t dofs[8] = {F.nq, F.nv, F.nv, der ? nn : (jac ? 6 * (int64_t)F.nv : F.nv),
                              der ? nn : 12 * (int64_t)F.njoints, nn, F.nv, 6 * (int64_t)F.njoints};
     const void* ptrs[8] = {A.q, A.v, A.a, A.out, A.out2, A.out3, A.out4, A.fext};
     const int64_t lds_[8] = {A.ldq, A.ldv, A.lda, A.ldout, A.ldout2, A.ldout3, A.ldout4, A.ldfext};
@@ -406,12 +409,13 @@ int launch_algo(brbd_model* m, int algo, KArgs& A, int layout, hipStream_t strea
         sk->fn[2][variant] && A.ldq == F.nq && A.ldv == F.nv && A.lda == F.nv && A.ldout == F.nv)
       klayout = 2;
     // (forward kinematics + Jacobians: q staged in, J and oMi streamed out in chunks of 64 rows)
-    if (sk && layout == BRBD_INSTANCE_MAJOR && !no_staged && algo == BRBD_ALGO_FK_JAC && sk->fn[2][variant] &&
+    if (sk && layout == BRBD_INSTANCE_MAJOR && !no_staged && jac && sk->fn[2][variant] &&
         A.ldq == F.nq && (!A.out || A.ldout == 6 * (int64_t)F.nv) && (!A.out2 || A.ldout2 == 12 * (int64_t)F.njoints))
       klayout = 2;
     if (sk && !sk->fn[klayout][variant]) sk = nullptr;
   }
-  if ((algo == BRBD_ALGO_RNEA_DERIV || algo == BRBD_ALGO_MINVERSE || algo == BRBD_ALGO_ABA_DERIV_PRODUCTS) && !sk) return 1;  // caller falls back to the table-driven kernel
+  if ((algo == BRBD_ALGO_RNEA_DERIV || algo == BRBD_ALGO_MINVERSE || algo == BRBD_ALGO_ABA_DERIV_PRODUCTS ||
+       algo == BRBD_ALGO_JOINT_JAC) && !sk) return 1;  // caller falls back to the table-driven kernel
   const bool stat = sk != nullptr;
   SpecFn sfn = stat ? sk->fn[klayout][variant] : nullptr;
   const int stage = stat && klayout == 2 ? sk->stage_doubles : 0;
@@ -691,7 +695,7 @@ int brbd_model_create(const brbd_model_desc* desc, int device, brbd_model** out)
       for (size_t k = 0; k < g_plugin_entries.size() && !m->spec; ++k)
         if (sig[pass] == g_plugin_entries[k]->signature) m->spec = g_plugin_entries[k];
     }
-    for (int a = 0; m->spec && a < 6 && e == hipSuccess; ++a) {
+    for (int a = 0; m->spec && a < 7 && e == hipSuccess; ++a) {
       const std::vector<double> ct = pack_constants(m->flat, m->spec->algo[a]);
       e = upload((void**)&m->d_ct[a], ct.data(), ct.size() * sizeof(double));
     }
@@ -1356,20 +1360,35 @@ int brbd_joint_jacobian(brbd_model* m, int64_t B, const double* q, int64_t ldq, 
     nchain = it->second.second;
   }
   auto run = [&](int64_t Bc, const double* dq, int64_t ldq_, double* dJ, int64_t ldJ_, hipStream_t st) -> int {
+    if (m->spec && m->use_spec && F.njoints <= 64) {  // model-compiled kernel (codegen/jjac.py)
+      KArgs K{};
+      fill_common(m, K, Bc);
+      K.rf = rf;
+      K.q = dq; K.ldq = ldq_; K.out = dJ; K.ldout = ldJ_;
+      for (int i = joint; i > 0; i = F.tab[i].parent) K.chain |= 1ull << i;
+      const int r = launch_algo(m, BRBD_ALGO_JOINT_JAC, K, layout, st);
+      if (r <= 0) return r;  // 1 = no compiled kernel applies
+    }
     KArgs A{};
     fill_common(m, A, Bc);
     A.prog3 = d_chain;
     A.nops3 = nchain;
     A.rf = rf;
+    if (F.nv <= 64)  // dofs of the support chain: the table-driven kernel zeroes only the other columns
+      for (int i = joint; i > 0; i = F.tab[i].parent)
+        for (int k = 0; k < F.tab[i].nvj; ++k) A.chain |= 1ull << (F.tab[i].idx_v + k);
     A.q = dq; A.ldq = ldq_; A.out = dJ; A.ldout = ldJ_;
     if (m->max_waves_jjac.load() == 0) m->max_waves_jjac.store(resident_waves(m, jjac_kernel<1>, WAVE));
     const int64_t mwj = m->max_waves_jjac.load();
     const int64_t grid = A.ntiles < mwj ? A.ntiles : mwj;
     const dim3 g((unsigned)grid), b(WAVE);
+    Timer tm{m, BRBD_ALGO_JOINT_JAC, st};
+    int rt = tm.begin();
+    if (rt) return rt;
     if (layout == BRBD_BATCH_MAJOR) hipLaunchKernelGGL(jjac_kernel<1>, g, b, 0, st, A);
     else hipLaunchKernelGGL(jjac_kernel<0>, g, b, 0, st, A);
     HIP_TRY(hipGetLastError());
-    return BRBD_OK;
+    return tm.end();
   };
   if (memspace == BRBD_DEVICE) return run(B, q, ldq, J, ldJ, s);
   const HostMat mats[2] = {{q, nullptr, ldq, F.nq, true, false}, {nullptr, J, ldJ, jd, false, true}};
@@ -1824,7 +1843,7 @@ int brbd_set_timing_period(brbd_model* m, int period) {
 }
 
 int brbd_kernel_time(brbd_model* m, int algo, int32_t* launches, double* total_ms) {
-  if (!m || algo < 0 || algo > 5) return fail(BRBD_ERR_INVALID_ARGUMENT, "bad model handle or algo");
+  if (!m || algo < 0 || algo > 6) return fail(BRBD_ERR_INVALID_ARGUMENT, "bad model handle or algo");
   DevGuard dg(m->device);
   std::vector<TimedLaunch> v;
   {

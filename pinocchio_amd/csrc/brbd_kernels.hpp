@@ -50,6 +50,7 @@ struct KArgs {
   uint32_t nb[8];                //   bytes spanned by q, v, a/tau, out, out2, out3, out4, fext (0 = absent)
   uint32_t ws_bytes;             //   bytes of the global park area of this launch
   unsigned long long* oob;       //   checking build (-DBRBD_SPEC_CHECK): out-of-range access counter, else NULL
+  unsigned long long chain;      //   compiled getJointJacobian: bit i = joint i is the joint or one of its ancestors
 };
 
 // ---- boundary matrices -------------------------------------------------------------------------
@@ -1137,7 +1138,11 @@ __global__ __launch_bounds__(WAVE) void jjac_kernel(const KArgs A) {
   for (int64_t tile = blockIdx.x; tile < A.ntiles; tile += gridDim.x) {
     const Mat<LAYOUT> q(const_cast<double*>(A.q), A.ldq, tile, A.B, lane);
     const Mat<LAYOUT> Jout(A.out, A.ldout, tile, A.B, lane);
-    for (int k = 0; k < 6 * A.nv; ++k) Jout.put(k, 0.0);
+    // columns off the support chain are zero (A.chain: bit c = dof c is on the chain, for nv <= 64;
+    // 0 = unknown: zero everything first, the chain's columns are then written twice)
+    for (int c = 0; c < A.nv; ++c)
+      if (A.chain == 0ull || !((A.chain >> c) & 1ull))
+        for (int r = 0; r < 6; ++r) Jout.put(6 * c + r, 0.0);
     double Rj[9], tj[3];
     for (int pass = 0; pass < 2; ++pass) {
       double R[9], t[3];

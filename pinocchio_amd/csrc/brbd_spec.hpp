@@ -37,12 +37,12 @@ enum : int { SF_R = 0, SF_T, SF_M, SF_C, SF_I, SF_ARM, SF_AXIS, SF_G };
 // Layout version of KArgs / SpecKernel / SpecEntry: kernels compiled separately (plugins built by
 // pinocchio_amd/codegen/plugin.py for models unknown when the library was built, loaded with
 // brbd_load_compiled_kernels) must agree with the library that launches them.
-#define BRBD_SPEC_ABI 6
+#define BRBD_SPEC_ABI 7
 
 struct SpecEntry {
   const char* name;
   const char* signature;  // tree + joint kinds + 0/1/-1 pattern of the constants (codegen/joints.py)
-  SpecKernel algo[6];     // BRBD_ALGO_RNEA, _ABA, _FK_JAC, _RNEA_DERIV, _MINVERSE, _ABA_DERIV_PRODUCTS
+  SpecKernel algo[7];     // BRBD_ALGO_RNEA, _ABA, _FK_JAC, _RNEA_DERIV, _MINVERSE, _ABA_DERIV_PRODUCTS, _JOINT_JAC
 };
 
 // ---- memory access of the model-compiled kernels ------------------------------------------------
@@ -374,6 +374,8 @@ DI double spec_rcp(double x) {
 #define OUTZ(k) do { if ((WANT & 17) == 17) mo.put(k, ldo8, 0.0); } while (0)
 #define OUT2Z(k) do { if ((WANT & 18) == 18) mo2.put(k, ldo28, 0.0); } while (0)
 #define OUT3Z(k) do { if ((WANT & 20) == 20) mo3.put(k, ldo38, 0.0); } while (0)
+// getJointJacobian (codegen/jjac.py): is joint i on the support chain the host passed?  (wave-uniform)
+#define ON_CHAIN(i) ((A.chain >> (i)) & 1ull)
 #define SINCOS(a, s, c) spec_sincos(a, s, c)
 #define RSQRT(a) rsqrt(a)
 #define RCP(a) spec_rcp(a)

@@ -297,3 +297,25 @@ def test_scratch_detector_sees_real_spills(tmp_path):
     subprocess.check_call([hipcc, "-O3", "--offload-arch=gfx950", "-c", "-o", str(obj), str(src)])
     counts = usage.scratch_instructions(str(obj))
     assert counts and max(counts.values()) > 0
+
+
+@pytest.mark.parametrize("name", ["arm7", "quadruped", "simple_humanoid"])
+def test_generated_joint_jacobian_bodies_match_oracle(name):
+    """codegen/jjac.py: one body per model, the joint a run-time chain mask, the frame a variant
+    (WANT 1 WORLD, 3 LOCAL, 5 LOCAL_WORLD_ALIGNED), against getJointJacobian restated by the oracle
+    (jacobian.hxx:175-283)."""
+    import ctypes
+    model = S.build(name)
+    mv = joints.ModelView(model)
+    O = oracle.Oracle(model)
+    q = inputs(model, 6)[0]
+    for want, rf in ((1, 0), (3, 1), (5, 2)):
+        ck = C.CpuKernel(mv, "jjac", want=want)
+        for j in sorted({1, model.njoints // 2, model.njoints - 1}):
+            mask, i = 0, j
+            while i > 0:
+                mask |= 1 << i
+                i = model.parents[i]
+            ctypes.c_ulonglong.in_dll(ck.lib, "spec_chain").value = mask
+            Jk = ck.run(q, None, None, (6 * model.nv, 0, 0))[0]
+            assert np.abs(Jk - O.joint_jacobian(q, j, rf)).max() < 1e-12

@@ -86,18 +86,23 @@ if "fext" in which:   # simple_humanoid with external forces (rnea.hxx:171-219, 
     print(json.dumps({"config": "simple_humanoid RNEA / ABA with external forces B=65536", "rnea_s": tr, "aba_s": ta,
                       "rnea_evals_per_s": B / tr, "aba_evals_per_s": B / ta, "rnea_GBps_algorithmic": byts / tr / 1e9}))
     pool.release()
-if "jjac" in which:   # arm7 end-effector Jacobian, LOCAL_WORLD_ALIGNED
-    m = S.arm7(); B = 1 << 20; pool = parallel.ModelPool(m, 1); dm = pool.device_model(0)
-    q, _, _ = inputs(m, B)
+if "jjac" in which:   # getJointJacobian of the last joint in the three reference frames
     import time
-    for _ in range(3): parallel.getJointJacobian(pool, q, m.njoints - 1, capi.LOCAL_WORLD_ALIGNED)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(10): parallel.getJointJacobian(pool, q, m.njoints - 1, capi.LOCAL_WORLD_ALIGNED)
-    torch.cuda.synchronize(); t = (time.perf_counter() - t0) / 10
-    byts = (m.nq + 6 * m.nv) * 8 * B
-    print(json.dumps({"config": "arm7 getJointJacobian(last joint, LOCAL_WORLD_ALIGNED) B=1048576 (wall time per call)",
-                      "s_per_call": t, "evals_per_s": B / t, "GBps_algorithmic": byts / t / 1e9}))
-    pool.release()
+    for m, B in ((S.arm7(), 1 << 20), (S.simple_humanoid(), 1 << 18)):
+        pool = parallel.ModelPool(m, 1); dm = pool.device_model(0)
+        q, _, _ = inputs(m, B)
+        for mode in ("compiled", "table-driven"):
+            dm.use_compiled(mode == "compiled")
+            for rf, rfname in ((capi.WORLD, "WORLD"), (capi.LOCAL, "LOCAL"), (capi.LOCAL_WORLD_ALIGNED, "LOCAL_WORLD_ALIGNED")):
+                for _ in range(3): parallel.getJointJacobian(pool, q, m.njoints - 1, rf)
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                for _ in range(10): parallel.getJointJacobian(pool, q, m.njoints - 1, rf)
+                torch.cuda.synchronize(); t = (time.perf_counter() - t0) / 10
+                byts = (m.nq + 6 * m.nv) * 8 * B
+                print(json.dumps({"config": f"{m.name} getJointJacobian(last joint, {rfname}) B={B}, {mode} (wall time per call)",
+                                  "s_per_call": t, "evals_per_s": B / t, "GBps_algorithmic": byts / t / 1e9}))
+        dm.use_compiled(True)
+        pool.release()
 
 def wall(fn, reps):
     import time

@@ -213,18 +213,22 @@ def main():
 
     def timed_steps(fn, k):
         # (fresh buffers and kernels: the first few dozen launches run slower -- first-touch page
-        # mappings, code-object load -- so warm up like the main region does)
-        for _ in range(max(args.warmup // 3, 20)):
+        # mappings, code-object load -- so warm up like the main region does; median of 3 regions)
+        for _ in range(max(k // 2, 20)):
             fn()
-        torch.cuda.synchronize()
-        t = time.perf_counter()
-        for _ in range(k):
-            fn()
-        torch.cuda.synchronize()
-        return evals_per_step * k / (time.perf_counter() - t)
+        rates = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(k):
+                fn()
+            torch.cuda.synchronize()
+            rates.append(evals_per_step * k / (time.perf_counter() - t))
+        return float(np.median(rates))
 
     # Side figures, each in a region of its own, reported in `config`, never in `value`:
-    k_side = max(args.steps // 4, 5)
+    # (each about 50 ms long whatever --steps is: a 5-step region measures the launch ramp, not the path)
+    k_side = int(min(max(0.05 / (elapsed / args.steps), 50), 2000))
     # (1) the same step in the reference's own instance-major (Eigen column-major) layout, device-resident
     qi, vi, ai = (x.t().contiguous().t() for x in (q, v, a))
     taui = tau.t().contiguous().t()
@@ -241,7 +245,7 @@ def main():
     td_rate = None
     if variant:
         dm.use_compiled(False)
-        td_rate = timed_steps(step, max(k_side // 4, 3))
+        td_rate = timed_steps(step, max(k_side // 8, 3))
         dm.use_compiled(True)
     # (3) end to end from HOST memory in the reference's calling convention (Eigen column-major
     # matrices in, results back in host memory; PCIe-inclusive, SURVEY 8d "timing hygiene")

@@ -47,6 +47,11 @@ WANTS = {"rnea": [1, 33], "aba": [1, 33], "fkjac": [1, 2, 3], "deriv": [31, 15],
 # RNEA: the staged values die as the walk consumes them while the hand-off records are born, and the
 # 20 doubles per lane hipcc cannot place go to scratch (humanoid, MI355X: 2.05e9 -> 2.49e9 evals/s in
 # the reference's layout; lower park budgets instead of the spills: 2.39e9).
+# Mode 2 (experiment: BRBD_CG_STAGE_MODE="rnea=2,aba=2" with BRBD_CG_GROUPED=rnea,aba,aba_local): no
+# staging, every lane fetches its own column a 128-byte line at a time when the walk first needs it
+# (csrc/brbd_spec.hpp: SpecIn<2, ., ., 2>).  Measured slower than register staging (humanoid, 65 536:
+# RNEA 22.9 against 20.1 us, ABA 34.6 against 28.7 us): 64 lanes x 64 different lines per load
+# instruction is texture-addresser time that the coalesced tile loads do not pay.
 # (minv: BATCH_MAJOR only -- INSTANCE_MAJOR calls of the nv x nv outputs run on batch-major copies anyway)
 # fkjac: layout 2 for models whose outputs are emitted in increasing element order (fkjac.monotone):
 # both outputs are streamed out in chunks of 64 rows

@@ -46,6 +46,10 @@ for _a in list(ALGOS):  # experiment hook: BRBD_CG_AHEAD_DERIV="glb=200,in=100"
             AHEAD_ALGO.setdefault(_a, {})[_kv.split("=")[0]] = int(_kv.split("=")[1])
 
 
+# algorithms whose INSTANCE_MAJOR kernels fetch their inputs a cache line per lane at a time (Emitter.group_inputs)
+# (experiment, off by default: measured slower than staging the tile, see codegen/build.py: STAGE_MODE)
+GROUPED = set(x for x in os.environ.get("BRBD_CG_GROUPED", "").split(",") if x)
+
 # algorithms whose early loads are placed at statement granularity (emit.Emitter.text, ``fine``)
 FINE = set(os.environ.get("BRBD_CG_FINE", "deriv,minv,prod").split(","))
 
@@ -146,6 +150,8 @@ def _build_one(mv: joints.ModelView, algo: str, reg_budget: Optional[int] = None
         lb = lb if lds_budget is None else lds_budget
         plan, lds, glb = plan_storage(dry[tail].parks, rb, lb, rl, rt, strict=(algo == "minv"))
         e = gen(mv, Emitter(plan), **kw)
+        if algo in GROUPED:
+            e.group_inputs()
         text = e.text(ahead, algo in FINE)
         k = Kernel(algo, text, list(e.const_list), lds, glb, dict(e.stats), len(e.visits))
         if len(ladder) == 1:
@@ -181,6 +187,12 @@ _CPU_SHELL = r"""
 #define IN_V(k) v[k]
 #define IN_X(k) x[k]
 #define IN_F(k) fx[k]
+#define GRP_Q(g, n) do { } while (0)
+#define GRP_V(g, n) do { } while (0)
+#define GRP_X(g, n) do { } while (0)
+#define IN_Q2(k, g, j, n) q[k]
+#define IN_V2(k, g, j, n) v[k]
+#define IN_X2(k, g, j, n) x[k]
 #ifndef WANT
 #define WANT 0
 #endif

@@ -29,6 +29,8 @@ from typing import Dict, List, Optional, Sequence, Tuple
 MACROS = """
   CT(k)                 k-th double of this kernel's packed constant table (wave-uniform -> s_load)
   IN_Q(k) IN_V(k) IN_X(k)   element k of q / v / third input (a or tau) of this lane's instance
+  GRP_Q(g, n) / IN_Q2(k, g, j, n)   (also V, X) fetch n of the 16-element group g of a matrix / its element
+                        j = element k of the matrix (Emitter.group_inputs; plain element loads outside layout 2)
   OUT(k, x)  OUT2(k, x)  OUT3(k, x)  store element k of the 1st / 2nd / 3rd output
   LD1(k) LD2(k) LD3(k)  element k of the 1st / 2nd / 3rd output matrix, read (in-place kernels)
   OUTSYM(k, x)          element k of the 1st output, mirror image of a stored one (WANT bit 1: x, else 0)
@@ -516,6 +518,42 @@ class Emitter:
                 out.append(V(names[j], v.neg))
                 j += 1
         return out
+
+    # ---- grouped input loads -----------------------------------------------------------------------
+    def group_inputs(self, gap: int = 1500, width: int = 16):
+        """Rewrite the element loads of q / v / the third input so that the INSTANCE_MAJOR kernels can
+        fetch them a cache line at a time.  In the reference's layout an instance is one contiguous
+        column: lane b's elements 16 g .. 16 g + 15 of a matrix are 128 consecutive bytes, which the
+        layout-2 kernels read with 8 back-to-back b128 loads per lane (GRP_Q(g, n): the line is
+        fetched once and consumed whole) when the first of them is needed, instead of staging the
+        whole tile before the first visit.  Every element load `IN_Q(k)` becomes
+        `IN_Q2(k, g, j, n)` = element j of that group; in the other layouts GRP_* is empty and IN_*2
+        is the plain element load.  A group whose uses lie more than ``gap`` statements apart is
+        fetched again (n counts the fetches) rather than held in registers in between."""
+        pat = re.compile(r"^const double (\w+) = IN_([QVX])\((\d+)\);$")
+        start, pos = [], 0
+        for v in self.visits:
+            start.append(pos)
+            pos += len(v.body)
+        last: Dict[tuple, Tuple[int, int]] = {}   # (matrix, group) -> (position of the last use, fetch number)
+        for vi, v in enumerate(self.visits):
+            new_pre = []
+            for line, kind, earliest in v.pre:
+                m = pat.match(line)
+                if not m:
+                    new_pre.append((line, kind, earliest))
+                    continue
+                name, which, k = m.group(1), m.group(2), int(m.group(3))
+                g, j = divmod(k, width)
+                key = (which, g)
+                if key not in last or start[vi] - last[key][0] > gap:
+                    n = last[key][1] + 1 if key in last else 0
+                    new_pre.append(("GRP_%s(%d, %d);" % (which, g, n), kind, earliest))
+                else:
+                    n = last[key][1]
+                last[key] = (start[vi], n)
+                new_pre.append(("const double %s = IN_%s2(%d, %d, %d, %d);" % (name, which, k, g, j, n), kind, earliest))
+            v.pre = new_pre
 
     # ---- output ----------------------------------------------------------------------------------
     def text(self, ahead: Optional[Dict[str, int]] = None, fine: bool = False) -> str:

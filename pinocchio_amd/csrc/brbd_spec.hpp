@@ -187,6 +187,8 @@ struct SpecIn : SpecMat<LAYOUT, AUX> {
   DI SpecIn(const double* base, unsigned bytes, unsigned ld8, int64_t b, unsigned long long* oob_, const SpecStage&, int)
       : SpecMat<LAYOUT, AUX>(base, bytes, ld8, b, oob_) {}
   DI void commit(const SpecStage&) {}
+  template <typename G> DI void grp(int, G&) const {}
+  template <typename G> DI double get2(int d, unsigned ld8, const G&, int) const { return this->get(d, ld8); }
 };
 template <int AUX, int N>
 struct SpecIn<2, AUX, N, 0> {  // staged into registers
@@ -201,6 +203,8 @@ struct SpecIn<2, AUX, N, 0> {  // staged into registers
     spec_stage_commit<N>(sc, x, [&](int d, double y) { r[d] = y; });
   }
   DI double get(int d, unsigned) const { return r[d]; }
+  template <typename G> DI void grp(int, G&) const {}
+  template <typename G> DI double get2(int d, unsigned ld8, const G&, int) const { return get(d, ld8); }
 };
 template <int AUX, int N>
 struct SpecIn<2, AUX, N, 1> {  // staged into the wave's global rows row0 .. row0 + N - 1
@@ -223,7 +227,46 @@ struct SpecIn<2, AUX, N, 1> {  // staged into the wave's global rows row0 .. row
     SPEC_CHECK(oob, voff + (unsigned)((row0 + d) * WAVE * 8), 8u, nbytes, 8);
     return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rr, voff, (unsigned)((row0 + d) * WAVE * 8), 0));
   }
+  template <typename G> DI void grp(int, G&) const {}
+  template <typename G> DI double get2(int d, unsigned ld8, const G&, int) const { return get(d, ld8); }
 };
+// MODE 2: no staging at all -- every lane fetches ITS OWN column a cache line at a time.  In the
+// reference's layout elements 16 g .. 16 g + 15 of a lane's instance are 128 consecutive bytes: 8
+// back-to-back b128 loads per lane (GRP_Q(g, n) in the generated body, codegen/emit.py:
+// group_inputs) bring the line in once and consume it whole, when the walk first needs one of
+// its elements, so the loads overlap the arithmetic as they do in BATCH_MAJOR instead of all
+// being waited for before the first visit.  Default cache policy: the 8 loads of a group and the
+// neighbouring lanes' groups share lines and meet in the L1 / L2.  Works for any leading dimension.
+template <bool ON>
+struct SpecGrp {};
+template <>
+struct SpecGrp<true> {
+  double2 v[8];
+};
+template <int AUX, int N>
+struct SpecIn<2, AUX, N, 2> {
+  __amdgpu_buffer_rsrc_t r;
+  unsigned voff, nbytes;
+  unsigned long long* oob;
+  DI SpecIn(const double* base, unsigned bytes, unsigned ld8, int64_t b, unsigned long long* oob_, const SpecStage&, int)
+      : r(spec_rsrc(base, bytes)), voff((unsigned)b * ld8), nbytes(bytes), oob(oob_) {}
+  DI void commit(const SpecStage&) {}
+  DI void grp(int g, SpecGrp<true>& G) const {  // (g is a literal at every call site: the bounds fold)
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (16 * g + 2 * i < N) {
+        const unsigned off = voff + (unsigned)(128 * g + 16 * i);
+        // (the last pair of an odd N reaches 8 bytes into the next column; past the very end of the
+        // matrix the range check of the buffer returns zeros for that half)
+        SPEC_CHECK(oob, off, 8u, nbytes, 10);
+        const v4u w = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+        const v2u x = {w.x, w.y}, y = {w.z, w.w};
+        G.v[i] = make_double2(__builtin_bit_cast(double, x), __builtin_bit_cast(double, y));
+      }
+  }
+  DI double get2(int, unsigned, const SpecGrp<true>& G, int j) const { return (j & 1) ? G.v[j >> 1].y : G.v[j >> 1].x; }
+};
+
 template <int LAYOUT, int AUX, int N>
 struct SpecOut : SpecMat<LAYOUT, AUX> {
   DI SpecOut(double* base, unsigned bytes, unsigned ld8, int64_t b, unsigned long long* oob_)
@@ -356,6 +399,14 @@ DI double spec_rcp(double x) {
 #define IN_Q(k) (mq.get(k, ldq8))
 #define IN_V(k) (mv.get(k, ldv8))
 #define IN_X(k) (mx.get(k, ldx8))
+// grouped fetches (codegen/emit.py: group_inputs): real in the layout-2 kernels with SPEC_STAGE_MODE 2,
+// empty everywhere else, where IN_*2 is the plain element load
+#define GRP_Q(g, n) SpecGrp<SPEC_GROUPED> qg_##g##_##n; mq.grp(g, qg_##g##_##n)
+#define GRP_V(g, n) SpecGrp<SPEC_GROUPED> vg_##g##_##n; mv.grp(g, vg_##g##_##n)
+#define GRP_X(g, n) SpecGrp<SPEC_GROUPED> xg_##g##_##n; mx.grp(g, xg_##g##_##n)
+#define IN_Q2(k, g, j, n) (mq.get2(k, ldq8, qg_##g##_##n, j))
+#define IN_V2(k, g, j, n) (mv.get2(k, ldv8, vg_##g##_##n, j))
+#define IN_X2(k, g, j, n) (mx.get2(k, ldx8, xg_##g##_##n, j))
 // external forces: only in the kernel variants with WANT bit 5 (a compile-time constant)
 #define IN_F(k) ((WANT & 32) ? mf.get(k, ldf8) : 0.0)
 #define OUT(k, val) do { if (WANT & 1) mo.put(k, ldo8, val); } while (0)
@@ -435,6 +486,7 @@ DI double spec_rcp(double x) {
   int64_t inst = tile * WAVE + lane;                                                                 \
   if (inst >= A.B) inst = A.B - 1;                                                                   \
   constexpr int LAY_ = (LAYOUT) == 2 ? 0 : (LAYOUT);  /* matrices that are not staged: per lane */   \
+  constexpr bool SPEC_GROUPED = (LAYOUT) == 2 && SPEC_STAGE_MODE == 2;                               \
   const SpecStage sc{tile, lane, reinterpret_cast<double*>(lds_area),                                \
                      A.ws + (int64_t)blockIdx.x * A.ws_stride + (int64_t)SPEC_GLB * WAVE,            \
                      (unsigned)((SPEC_NQ + SPEC_NV + SPEC_NX) * WAVE * 8)};                           \

@@ -260,7 +260,7 @@ int brbd_minverse(brbd_model* m, int64_t B, const double* q, int64_t ldq, double
  * (algorithm/aba-derivatives.hxx:381-454): three (nv * nv) x B matrices, per instance column-major;
  * ddq_dtau = Minv, FULL and symmetric (:449-450); ddq_dq = -Minv dtau_dq, ddq_dv = -Minv dtau_dv at
  * the acceleration ddq = aba(q, v, tau) (:452-453), which is returned in `ddq` (nv x B) unless NULL.
- * Every element is written.  Depth-first numbering; nv <= 48 in this version. */
+ * Every element is written.  Depth-first numbering (see brbd_minverse); nv <= 96. */
 int brbd_aba_derivatives(brbd_model* m, int64_t B, const double* q, int64_t ldq, const double* v, int64_t ldv,
                          const double* tau, int64_t ldtau, double* ddq_dq, int64_t lddq, double* ddq_dv, int64_t lddv,
                          double* ddq_dtau, int64_t lddtau, double* ddq, int64_t ldddq, int layout, int memspace,

@@ -21,8 +21,10 @@ from typing import List
 from . import joints as J
 from .emit import ZERO, Emitter
 
+import os
+
 MINV_REGS = 180   # doubles of Minv's upper triangle that may stay in registers
-BLOCK_REGS = 96    # doubles of a column group's factor blocks (both matrices)
+BLOCK_REGS = int(os.environ.get("BRBD_CG_PROD_BLOCK", "150"))    # doubles of a column group's factor blocks (both matrices)
 
 
 def _coupled(mv: J.ModelView):

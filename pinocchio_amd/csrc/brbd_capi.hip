@@ -103,7 +103,7 @@ struct brbd_model {
   std::atomic<int> max_waves[7] = {};
   std::atomic<int> max_waves_spec[7] = {};
   std::atomic<int> max_waves_jjac{0};
-  std::atomic<int> max_waves_f4[4] = {};  // minverse, integrate, aba-derivative products (nv <= 24, nv <= 48)
+  std::atomic<int> max_waves_f4[5] = {};  // minverse, integrate, aba-derivative products (nv <= 24, <= 48, <= 96)
   std::map<int, std::pair<Op*, int>> chains;  // brbd_joint_jacobian: support chain of a joint (device)
   // model-compiled kernels (brbd_spec.hpp), when the model's signature is registered
   const SpecEntry* spec = nullptr;
@@ -1631,7 +1631,7 @@ int brbd_aba_derivatives(brbd_model* m, int64_t B, const double* q, int64_t ldq,
   if (ddq && (rc = check_mat("ddq", ddq, ldddq, F.nv, B, layout))) return rc;
   if (!F.depth_first)
     return fail(BRBD_ERR_UNSUPPORTED, "computeABADerivatives needs depth-first joint numbering (contiguous subtrees)");
-  if (F.nv > 48) return fail(BRBD_ERR_UNSUPPORTED, "computeABADerivatives: models with nv > 48 are not supported yet");
+  if (F.nv > 96) return fail(BRBD_ERR_UNSUPPORTED, "computeABADerivatives: models with nv > 96 are not supported yet");
   if (B == 0) return BRBD_OK;
   DevGuard dg(m->device);
   if (!dg.ok) return fail(BRBD_ERR_RUNTIME, "hipSetDevice failed");
@@ -1661,17 +1661,22 @@ int brbd_aba_derivatives(brbd_model* m, int64_t B, const double* q, int64_t ldq,
     F4Args A{};
     fill_f4(m, A, Bc);
     A.out = o1; A.ldout = lo1; A.out2 = o2; A.ldout2 = lo2; A.minv = o3; A.ldminv = lo3;
-    // (4 columns of both factors in registers for nv <= 24, 2 for nv <= 48: about 200 doubles)
-    const int grid = F.nv <= 24 ? f4_grid(m, m->max_waves_f4[2], aba_deriv_product_kernel<1, 24, 4>, A.ntiles)
-                                : f4_grid(m, m->max_waves_f4[3], aba_deriv_product_kernel<1, 48, 2>, A.ntiles);
+    // (4 columns of both factors in registers for nv <= 24, 2 for nv <= 48, 1 for nv <= 96: about 200 doubles)
+    const int cls = F.nv <= 24 ? 0 : (F.nv <= 48 ? 1 : 2);
+    const int grid = cls == 0 ? f4_grid(m, m->max_waves_f4[2], aba_deriv_product_kernel<1, 24, 4>, A.ntiles)
+                   : cls == 1 ? f4_grid(m, m->max_waves_f4[3], aba_deriv_product_kernel<1, 48, 2>, A.ntiles)
+                              : f4_grid(m, m->max_waves_f4[4], aba_deriv_product_kernel<1, 96, 1>, A.ntiles);
     Timer tm{m, BRBD_ALGO_ABA_DERIV_PRODUCTS, st};
     if ((r = tm.begin())) return r;
+    const dim3 g_(grid), b_(WAVE);
     if (layout == BRBD_BATCH_MAJOR) {
-      if (F.nv <= 24) hipLaunchKernelGGL((aba_deriv_product_kernel<1, 24, 4>), dim3(grid), dim3(WAVE), 0, st, A);
-      else hipLaunchKernelGGL((aba_deriv_product_kernel<1, 48, 2>), dim3(grid), dim3(WAVE), 0, st, A);
+      if (cls == 0) hipLaunchKernelGGL((aba_deriv_product_kernel<1, 24, 4>), g_, b_, 0, st, A);
+      else if (cls == 1) hipLaunchKernelGGL((aba_deriv_product_kernel<1, 48, 2>), g_, b_, 0, st, A);
+      else hipLaunchKernelGGL((aba_deriv_product_kernel<1, 96, 1>), g_, b_, 0, st, A);
     } else {
-      if (F.nv <= 24) hipLaunchKernelGGL((aba_deriv_product_kernel<0, 24, 4>), dim3(grid), dim3(WAVE), 0, st, A);
-      else hipLaunchKernelGGL((aba_deriv_product_kernel<0, 48, 2>), dim3(grid), dim3(WAVE), 0, st, A);
+      if (cls == 0) hipLaunchKernelGGL((aba_deriv_product_kernel<0, 24, 4>), g_, b_, 0, st, A);
+      else if (cls == 1) hipLaunchKernelGGL((aba_deriv_product_kernel<0, 48, 2>), g_, b_, 0, st, A);
+      else hipLaunchKernelGGL((aba_deriv_product_kernel<0, 96, 1>), g_, b_, 0, st, A);
     }
     HIP_TRY(hipGetLastError());
     return tm.end();

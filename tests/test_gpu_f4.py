@@ -17,6 +17,13 @@ MODELS = [S.simple_humanoid(), S.quadruped(), S.arm7(), S.talos_like(),
 IDS = [m.name for m in MODELS]
 
 
+# ddq_dq / ddq_dv = -Minv * dtau_dq|dv: north_star's 1e-10.  Measured on MI355X over 2048 instances of
+# each model above (tools/f4_errors.py, profiles/r03_f4_errors.json): worst 9e-13 in this metric
+# (1.4e-12 per instance in the Frobenius norm), on the talos-class model whose cond(M) reaches 1e5;
+# every other model stays below 1.1e-13.  Round 2 tested these two at 1e-9 without a measurement.
+TOL_DDQ = 1e-10
+
+
 def _rel(x, y):
     return np.abs(x - y).max() / max(1.0, np.abs(y).max())
 
@@ -36,7 +43,7 @@ def test_f4_host_memspace_vs_oracle(model, order):
     dq, dv, Minv, ddq = parallel.computeABADerivatives(pool, qq, vv, tt, want_ddq=True)
     rq, rv, rM, rdd = O.aba_derivatives(q, v, tau)
     assert _rel(ddq, rdd) < 1e-10 and _rel(Minv, rM) < 1e-10
-    assert _rel(dq, rq) < 1e-9 and _rel(dv, rv) < 1e-9
+    assert _rel(dq, rq) < TOL_DDQ and _rel(dv, rv) < TOL_DDQ
     pool.release()
 
 
@@ -62,7 +69,7 @@ def test_f4_device_memspace_rollout_step(layout):
     torch.cuda.synchronize()
     idx = np.random.default_rng(0).choice(B, 64, replace=False)
     rq, rv, rM, rdd = O.aba_derivatives(q[:, idx], v[:, idx], tau[:, idx])
-    assert _rel(dq[:, idx].cpu().numpy(), rq) < 1e-9 and _rel(dv[:, idx].cpu().numpy(), rv) < 1e-9
+    assert _rel(dq[:, idx].cpu().numpy(), rq) < TOL_DDQ and _rel(dv[:, idx].cpu().numpy(), rv) < TOL_DDQ
     assert _rel(Minv[:, idx].cpu().numpy(), rM) < 1e-10
     v1r = v[:, idx] + dt * rdd
     assert np.abs(q1[:, idx].cpu().numpy() - O.integrate(q[:, idx], dt * v1r)).max() < 1e-12
@@ -93,4 +100,20 @@ def test_f4_argument_checks():
     assert parallel.integrate(pool, z, z).shape == (3, 4)      # integrate needs no ordering
     with pytest.raises(capi.BrbdInvalidArgument):
         parallel.integrate(pool, z, np.zeros((2, 4)))
+    pool.release()
+
+
+def test_f4_more_than_48_dofs():
+    """computeABADerivatives beyond the nv <= 48 of round 2 (now <= 96): a 70-dof random tree."""
+    model = S.random_tree(777, 52, kinds=[M.JOINT_RX, M.JOINT_RY, M.JOINT_RZ, M.JOINT_SPHERICAL, M.JOINT_PX])
+    assert 48 < model.nv <= 96
+    pool = parallel.ModelPool(model, 1)
+    O = oracle.Oracle(model)
+    q, v, tau = inputs(model, 70, 5)
+    for order in "FC":
+        qq, vv, tt = (np.asarray(x, order=order) for x in (q, v, tau))
+        dq, dv, Minv, ddq = parallel.computeABADerivatives(pool, qq, vv, tt, want_ddq=True)
+        rq, rv, rM, rdd = O.aba_derivatives(q, v, tau)
+        assert _rel(ddq, rdd) < 1e-10 and _rel(Minv, rM) < 1e-10
+        assert _rel(dq, rq) < TOL_DDQ and _rel(dv, rv) < TOL_DDQ
     pool.release()

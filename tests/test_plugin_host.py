@@ -14,8 +14,8 @@ def test_build_and_load_a_plugin_for_an_unregistered_model(tmp_path):
     out = str(tmp_path / "libbrbd_spec_tiny.so")
     rep = plugin.build_plugin(model, out, name="tiny tree!")   # the name is sanitised into an identifier
     assert rep["name"] == "tiny_tree__p" and os.path.exists(out)
-    assert len(rep["kernels"]) == 26 and not rep["refused"]   # rnea 5, aba 5, fkjac 9, deriv 4, minv 2, prod 1
-    assert not any(int(k["ScratchSize"]) > 0 and int(k["SGPRs Spill"]) > 8 for k in rep["kernels"])
+    assert len(rep["kernels"]) == 35 and not rep["refused"]   # rnea 5, aba 5, fkjac 9, deriv 4, minv 2, prod 1, jjac 9
+    assert not any(int(k["ScratchInsts"]) != 0 and int(k["SGPRs Spill"]) > 8 for k in rep["kernels"])
     assert capi.load_compiled_kernels(out) == 1
     assert capi.load_compiled_kernels(out) == 0                # same signature: not added twice
 

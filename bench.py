@@ -45,6 +45,8 @@ def parse():
                    help="kernel plugin(s) built by `python -m pinocchio_amd.codegen.plugin` for this model")
     p.add_argument("--repeats", type=int, default=9,
                    help="the --steps long timed region is run this many times; the line reports the median")
+    p.add_argument("--armature", type=float, default=0.0,
+                   help="rotor inertia on every 1-dof joint (model.armature; 0 = none, the reference benchmark's model)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
     return p.parse_args()
@@ -134,6 +136,10 @@ def main():
     for path in args.plugin:
         capi.load_compiled_kernels(path)
     model = load_model(args.model)
+    if args.armature:
+        for j in range(1, model.njoints):
+            if model.nvs[j] == 1:
+                model.armature[model.idx_vs[j]] = args.armature
     do_rnea, do_aba = "rnea" in args.algo, "aba" in args.algo
     B = args.batch
     pool = parallel.ModelPool(model, 1)
@@ -281,7 +287,7 @@ def main():
         avg_a = ms_a / max(n_a, 1)
         pm = {}
         tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tj) and args.model == "simple_humanoid" and B == 65536:
+        if os.path.exists(tj) and args.model == "simple_humanoid" and B == 65536 and not args.armature:
             try:
                 with open(tj) as f:
                     pm = json.load(f)
@@ -326,7 +332,7 @@ def main():
             roof = {"bound": "hbm", "kernel": kname, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": bytes_per_eval * B, "traffic": traffic,
                     "traffic_source": tsrc, "fp64": fp64, "hbm": hbm}
-        headline = args.model == "simple_humanoid" and B == 65536 and args.algo == "rnea+aba"
+        headline = args.model == "simple_humanoid" and B == 65536 and args.algo == "rnea+aba" and not args.armature
         out = {
             "metric": ("ABA/RNEA evals/sec, humanoid fp64 batch 65536" if headline
                        else f"{args.algo} evals/sec, {model.name} fp64 batch {B} per GPU"),
@@ -345,6 +351,7 @@ def main():
                 "workload": f"{model.name} (nq {model.nq} / nv {model.nv}) {args.algo.upper().replace('+', ' + ')}, "
                             f"batch {B} per GPU, fp64, device-resident BATCH_MAJOR",
                 "batch_per_gpu": B,
+                "armature": args.armature,
                 "evals_per_step_per_gpu": evals_per_step,
                 "rnea_kernel_ms": avg_r if do_rnea else None, "aba_kernel_ms": avg_a if do_aba else None,
                 "repeats": len(regions),

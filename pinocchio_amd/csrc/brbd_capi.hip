@@ -418,6 +418,10 @@ int launch_algo(brbd_model* m, int algo, KArgs& A, int layout, hipStream_t strea
        algo == BRBD_ALGO_JOINT_JAC) && !sk) return 1;  // caller falls back to the table-driven kernel
   const bool stat = sk != nullptr;
   SpecFn sfn = stat ? sk->fn[klayout][variant] : nullptr;
+  {  // experiment (brbd_spec.hpp: BRBD_TILE_LANES): kernels built with 32-instance tiles
+    static const bool half = getenv("BRBD_HALF_TILE") && getenv("BRBD_HALF_TILE")[0] == '1';
+    if (half && stat && algo == BRBD_ALGO_RNEA && klayout == 1) A.ntiles = (A.B + 31) / 32;
+  }
   const int stage = stat && klayout == 2 ? sk->stage_doubles : 0;
   std::atomic<int>& mw_cache = stat ? m->max_waves_spec[algo] : m->max_waves[algo];
   int mw = mw_cache.load(std::memory_order_relaxed);

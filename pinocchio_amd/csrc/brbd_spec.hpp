@@ -431,8 +431,16 @@ DI double spec_rcp(double x) {
 #define RSQRT(a) rsqrt(a)
 #define RCP(a) spec_rcp(a)
 #define FMA(a, b, c) __builtin_fma(a, b, c)
-#define PK_LDS_ST2(p, a, b) lds2[(p) * WAVE] = make_double2(a, b)
-#define PK_LDS_LD2(p, a, b) do { const double2 t_ = lds2[(p) * WAVE]; a = t_.x; b = t_.y; } while (0)
+// Experiment (tools/cg_variant.sh EXTRA=-DBRBD_TILE_LANES=32 + BRBD_HALF_TILE=1 at run time, BATCH_MAJOR
+// RNEA only): tiles of 32 instances, the upper half of every wave idle, so that 65 536 instances are
+// 2 048 waves = TWO per SIMD.  It measures what a second resident wave hides of the first one's
+// waits without shortening anybody's program -- the upper bound of what splitting an instance over
+// two lanes could win on top of its shorter programs.
+#ifndef BRBD_TILE_LANES
+#define BRBD_TILE_LANES WAVE
+#endif
+#define PK_LDS_ST2(p, a, b) lds2[(p) * BRBD_TILE_LANES] = make_double2(a, b)
+#define PK_LDS_LD2(p, a, b) do { const double2 t_ = lds2[(p) * BRBD_TILE_LANES]; a = t_.x; b = t_.y; } while (0)
 #define PK_GLB_ST2(p, a, b) do { SPEC_CHECK(A.oob, wsoff + (unsigned)(p) * (WAVE * 16u), 16u, A.ws_bytes, 5); spec_park_st(wsr, wsoff, p, a, b); } while (0)
 #define PK_GLB_LD2(p, a, b) do { SPEC_CHECK(A.oob, wsoff + (unsigned)(p) * (WAVE * 16u), 16u, A.ws_bytes, 6); spec_park_ld(wsr, wsoff, p, a, b); } while (0)
 // Visit boundary: nothing is scheduled across it, so the table loads of later visits are not
@@ -468,7 +476,7 @@ DI double spec_rcp(double x) {
 #define BRBD_SPEC_PROLOGUE(LDS_PAIRS)                                                                \
   const int lane = threadIdx.x;                                                                      \
   const double BRBD_CONSTANT* ct = as_constant(A.ctab);                                              \
-  __shared__ double2 lds_area[(LDS_PAIRS) > 0 ? (LDS_PAIRS) * WAVE : 1];                             \
+  __shared__ double2 lds_area[(LDS_PAIRS) > 0 ? (LDS_PAIRS) * BRBD_TILE_LANES : 1];                  \
   double2* const lds2 = lds_area + lane;                                                             \
   const __amdgpu_buffer_rsrc_t wsr = spec_rsrc(A.ws, A.ws_bytes);                                    \
   const unsigned wsoff = blockIdx.x * (unsigned)(A.ws_stride * 8) + (unsigned)lane * 16u;            \
@@ -483,7 +491,8 @@ DI double spec_rcp(double x) {
 // SPEC_GLB (doubles per lane of the global park area, after which the staging rows start) are
 // constants of the generated kernel template (codegen/build.py).
 #define BRBD_SPEC_TILE(LAYOUT)                                                                       \
-  int64_t inst = tile * WAVE + lane;                                                                 \
+  if (BRBD_TILE_LANES < WAVE && lane >= BRBD_TILE_LANES) return;                                     \
+  int64_t inst = tile * BRBD_TILE_LANES + lane;                                                      \
   if (inst >= A.B) inst = A.B - 1;                                                                   \
   constexpr int LAY_ = (LAYOUT) == 2 ? 0 : (LAYOUT);  /* matrices that are not staged: per lane */   \
   constexpr bool SPEC_GROUPED = (LAYOUT) == 2 && SPEC_STAGE_MODE == 2;                               \

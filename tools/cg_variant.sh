@@ -11,7 +11,7 @@ env "$@" python -m pinocchio_amd.codegen.build --out $D/gen --models $MODEL --va
 # kernels whose generated text equals the main build's (pinocchio_amd/csrc/gen, same digest line) reuse
 # its objects -- only when no flag / text experiment below is active
 REUSE=""
-if [ -z "$EXTRA$KATTR$NOBAR$DEFER_OUT" ]; then
+if [ -z "$EXTRA$KATTR$NOBAR$DEFER_OUT$HALF" ]; then
   for f in $D/gen/spec_*.hip; do
     b=$(basename $f)
     if cmp -s $f pinocchio_amd/csrc/gen/$b && [ -f pinocchio_amd/csrc/gen/${b%.hip}.o ]; then
@@ -39,6 +39,8 @@ assert rest[-1] == "VISIT_END();"
 open(p, "w").write("\n".join(rest[:-1] + outs + ["VISIT_END();", ""]))
 PY
 done; done
+# HALF="rnea": tiles of 32 instances for these algorithms' kernels (brbd_spec.hpp: BRBD_TILE_LANES; run with BRBD_HALF_TILE=1)
+for alg in $HALF; do for f in $D/gen/*_$alg.kern.inc; do sed -i '1i #undef BRBD_TILE_LANES\n#define BRBD_TILE_LANES 32' $f; done; done
 if [ -n "$KATTR" ]; then sed -i "s/__launch_bounds__(WAVE)/__launch_bounds__(WAVE) $KATTR/" $D/gen/*.kern.inc; fi
 sed -e 's#"gen/registry.inc"#"'$D'/gen/registry.inc"#' -e 's#"../../include/brbd.h"#"brbd.h"#' pinocchio_amd/csrc/brbd_capi.hip > $D/gen/spec_capi.hip
 (ls $D/gen/spec_*.hip 2>/dev/null || true) | xargs -r -P 8 -I{} sh -c "/opt/rocm/bin/hipcc $FLAGS -I include -I $D/gen -c -o {}.o {} -Rpass-analysis=kernel-resource-usage 2> {}.usage || { grep error {}.usage; exit 255; }"

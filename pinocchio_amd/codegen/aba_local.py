@@ -46,6 +46,10 @@ TAIL_PARK_SC = os.environ.get("BRBD_CG_LTAILSC", "0") == "1"
 PARK_BIAS = os.environ.get("BRBD_CG_LBIAS", "0") == "1"
 # ... and sin / cos of the joint angle: parked (2 doubles) or evaluated again (~35 instructions)
 RECOMPUTE_SINCOS = os.environ.get("BRBD_CG_LRESINCOS", "0") == "1"
+# hand-off record: UDinv along the axis of a 1-dof joint without armature is U[ax] / U[ax] = 1, not stored;
+# the joint velocity is parked with it or read again from the boundary matrix in pass 3
+UD_AXIS_ONE = os.environ.get("BRBD_CG_LUDONE", "1") == "1"
+REREAD_VQ = os.environ.get("BRBD_CG_LREREADVQ", "1") == "1"
 # inertia transform behind a plain axis rotation through the double-angle form: 4 % fewer operations,
 # measured (humanoid, 65 536, same box): BATCH_MAJOR ABA 22.87 -> 22.66 us, but the INSTANCE_MAJOR
 # kernel, which stages its tile in registers, then spills 90 instead of 40 VGPRs: 28.8 -> 34.4 us.
@@ -212,10 +216,12 @@ def generate(mv: J.ModelView, e: Emitter, tail: int = None) -> Emitter:
         Dinv = [[e.rcp(D[0][0])]] if nv == 1 else spd_inverse(e, D)
         UD = [[e.dot([U[r][k] for r in range(nv)], [Dinv[r][c] for r in range(nv)]) for k in range(6)]
               for c in range(nv)]
+        ax = unit_axis(S[0]) if (nv == 1 and arm[0].is_zero()) else None
+        if ax is not None and UD_AXIS_ONE:
+            UD[0][ax] = ONE  # U[ax] / D with D = U[ax]: 1 (the quotient's rounding aside), and one double less to hand over
         kk = [e.sub(e.dot(Dinv[r], u), A.dot6(e, UD[r], bias)) for r in range(nv)]
         if not want_parent:
             return UD, kk, None
-        ax = unit_axis(S[0]) if (nv == 1 and arm[0].is_zero()) else None
         Ia2 = list(Ia)
         for a_ in range(6):
             for b_ in range(a_, 6):
@@ -366,7 +372,7 @@ def generate(mv: J.ModelView, e: Emitter, tail: int = None) -> Emitter:
             if PARK_BIAS:
                 bias = h[pos:pos + 6]
                 pos += 6
-            else:
+            elif not REREAD_VQ:
                 vq = h[pos:pos + nv]
                 pos += nv
             sc = tuple(h[pos:pos + 2]) if len(h) >= pos + 2 else None
@@ -415,7 +421,7 @@ def generate(mv: J.ModelView, e: Emitter, tail: int = None) -> Emitter:
             UD, kk, acc = project(i, S, bias, Ia, pA)
             if i not in in_tail:
                 rec = [x for col in UD for x in col] + kk
-                rec += bias if PARK_BIAS else vq
+                rec += bias if PARK_BIAS else ([] if REREAD_VQ else vq)
                 if sc is not None and not RECOMPUTE_SINCOS:
                     rec += list(sc)
                 hand[i] = e.park(rec, "hand")

@@ -126,7 +126,7 @@ def build_kernel(mv: joints.ModelView, algo: str, reg_budget: Optional[int] = No
 # area costs more than a longer tail (MI355X, humanoid: 40 doubles per lane in global parks 29.3 us,
 # none 25.1 us; tails of 3 instead of 2 joints 26.2 us), so the first rung that keeps every park on
 # chip within the register estimate wins.
-LADDER_LOCAL = [(t, b) for t in (2, 3, 4, 5) for b in ((64, 80, 140, 64), (48, 80, 140, 64), (48, 80, 120, 64), (48, 80, 100, 64))]
+LADDER_LOCAL = [(t, b) for t in (0, 1, 2, 3, 4, 5) for b in ((64, 80, 140, 64), (48, 80, 140, 64), (48, 80, 120, 64), (48, 80, 100, 64))]
 
 
 def _build_one(mv: joints.ModelView, algo: str, reg_budget: Optional[int] = None,

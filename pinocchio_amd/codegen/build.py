@@ -57,6 +57,15 @@ WANTS = {"rnea": [1, 33], "aba": [1, 33], "fkjac": [1, 2, 3], "deriv": [31, 15],
 # both outputs are streamed out in chunks of 64 rows
 LAYOUTS = {"rnea": (0, 1, 2), "aba": (0, 1, 2), "fkjac": (0, 1, 2), "deriv": (0, 1), "minv": (1,), "prod": (1,),
            "jjac": (0, 1, 2)}
+# Mode 3 (experiment: BRBD_CG_STAGE_MODE="rnea=3,aba=3"): chunked staging -- the inputs arrive 8 dofs x 64
+# instances at a time through a small LDS window, a prefetch distance ahead of the visit that consumes
+# them, so that the loads overlap the walk as they do in BATCH_MAJOR (csrc/brbd_spec.hpp:
+# SpecIn<2, ., ., 3>; these kernels run a body of their own, compile.build_kernel(chunked=True), with
+# the LDS parks capped at 70 doubles per lane, that shares the constant table of the other layouts').
+# Measured much slower than staging the tile up front (humanoid, 65 536, MI355X: 1.92e9 against
+# 2.96e9 evals/s for the RNEA + ABA step): every group fetch touches a 64-byte piece of EVERY cache
+# line of the tile, 4.5 times over the kernel with other traffic in between, so the lines are
+# fetched again and again, while the up-front staging reads each line exactly once.
 STAGE_MODE = {"rnea": 0, "aba": 0, "fkjac": 0, "deriv": 0, "minv": 0, "prod": 0, "jjac": 0}
 STAGED_WANTS = [1]  # (the external-force variants read 6 * njoints more rows per lane anyway: not staged)
 
@@ -77,6 +86,11 @@ def _stage_mode(algo: str, model) -> int:
     if algo == "aba" and STAGE_MODE[algo] == 0 and model.nq + 2 * model.nv > 108:
         return 1
     return STAGE_MODE[algo]
+
+
+def _fallback_mode(algo: str, model) -> int:
+    """staging mode of a model whose chunked body cannot share the constant table"""
+    return 1 if (algo == "aba" and model.nq + 2 * model.nv > 108) else 0
 
 
 def _staged_wants(algo: str):
@@ -124,9 +138,22 @@ def _emit_algo(args):
     stream = 1 if algo in ("fkjac", "jjac") else 0                # outputs leave in chunks of 64 rows
     stage_pairs = (max(rows[:3] + ((64,) if stream else rows[3:])) + 1) // 2
     stage_mode = _stage_mode(algo, model)
+    k2 = None
+    if staged and stage_mode == 3:
+        k2 = C.build_kernel(mv, algo, chunked=True, like=k)
+        if k2 is None:
+            stage_mode = _fallback_mode(algo, model)
     stage_rows = (nq + 2 * nv) if (staged and stage_mode == 1) else 0
     body = "%s_%s.inc" % (ident, algo)
     _write(os.path.join(out_dir, body), k.text)
+    body2 = "%s_%s.chunk.inc" % (ident, algo)
+    if k2 is not None:
+        _write(os.path.join(out_dir, body2), k2.text)
+    elif os.path.exists(os.path.join(out_dir, body2)):
+        os.remove(os.path.join(out_dir, body2))
+    glb = max(k.glb, k2.glb if k2 is not None else 0)
+    out_pairs = (max(((64,) if stream else rows[3:])) + 1) // 2   # the output leaves through LDS at the end
+    lds2_pairs = max(k2.lds // 2 + C.CHUNK_WINDOW_PAIRS, out_pairs) if k2 is not None else max(k.lds // 2, stage_pairs)
     kern = "%s_%s.kern.inc" % (ident, algo)
     kern_text = ("\n".join([
             "// GENERATED by pinocchio_amd/codegen/build.py -- do not edit.",
@@ -138,21 +165,28 @@ def _emit_algo(args):
                 2 if algo in ("rnea", "aba") else 0),
             "  // rows of q, v, the third input and the first output; staging of the layout-2 kernels",
             "  constexpr int SPEC_NQ = %d, SPEC_NV = %d, SPEC_NX = %d, SPEC_NO = %d, SPEC_STAGE_MODE = %d, SPEC_GLB = %d;" % (
-                rows + (stage_mode, k.glb)),
+                rows + (stage_mode, glb)),
+            "  constexpr int SPEC_LDS_PARK = LAYOUT == 2 ? %d : %d;  // doubles per lane of the park area (the staging window follows it)"
+            % (k2.lds if k2 is not None else k.lds, k.lds),
             ] + (["  constexpr int SPEC_NO2 = %d, SPEC_OUT_STREAM = %d;  // (shadow the defaults of brbd_spec.hpp)" % (rows2, stream)]
                  if stream else []) + [
-            "  BRBD_SPEC_PROLOGUE(LAYOUT == 2 ? %d : %d)" % (max(k.lds // 2, stage_pairs), k.lds // 2),
+            "  BRBD_SPEC_PROLOGUE(LAYOUT == 2 ? %d : %d)" % (lds2_pairs, k.lds // 2),
             "  {  // one tile of 64 instances per workgroup: no loop, nothing for LICM to hoist",
             "    const int64_t tile = A.tile0 + blockIdx.x;",
             "    BRBD_SPEC_TILE(LAYOUT)",
+            ] + (['#include "%s"' % body] if k2 is None else [
+            "    if constexpr (LAYOUT == 2) {  // chunked staging: a body of its own, same constant table",
+            '#include "%s"' % body2,
+            "    } else {",
             '#include "%s"' % body,
+            "    }"]) + [
             "    BRBD_SPEC_EPILOGUE();",
             "  }",
             "}",
             ""]))
     _write(os.path.join(out_dir, kern), kern_text)
     import hashlib
-    digest = hashlib.sha1((k.text + kern_text).encode()).hexdigest()[:16]
+    digest = hashlib.sha1((k.text + (k2.text if k2 is not None else "") + kern_text).encode()).hexdigest()[:16]
     for layout in layouts:
         for w in (WANTS[algo] if layout != 2 else _staged_wants(algo)):
             _write(os.path.join(out_dir, "spec_%s_%s_%d_%d.hip" % (ident, algo, layout, w)), "\n".join([
@@ -168,7 +202,7 @@ def _emit_algo(args):
                 ""]))
     from .emit import encode_const
     gather = ", ".join("%d,%d,%d,%d" % encode_const(ident, FIELD) for ident in k.const_list) or "0"
-    return algo, gather, len(k.const_list), k.lds, k.glb, stage_rows, layouts
+    return algo, gather, len(k.const_list), k.lds, glb, stage_rows, layouts
 
 
 # the armature enters these algorithms only; the "a" variant (armature of 1-dof joints generic) shares

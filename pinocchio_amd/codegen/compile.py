@@ -60,6 +60,9 @@ FINE = set(os.environ.get("BRBD_CG_FINE", "deriv,minv,prod").split(","))
 # scratch beyond ~200 doubles (512 registers per lane at one wave per SIMD, minus addressing).
 LADDER = {"aba": [(48, 80, 100, 64), (32, 80, 100, 64), (16, 80, 100, 64), (16, 80, 80, 64)],
           "aba_local": [(48, 80, 100, 64), (32, 80, 100, 64), (16, 80, 100, 64), (16, 80, 80, 64)],
+          # rnea: its register pressure is low (about 90 doubles live); a model whose path state overflows
+          # the LDS gets more register parks rather than the wave's global area (first rung without global parks)
+          "rnea": [(40, 80, 0), (56, 80, 0), (72, 80, 0), (96, 80, 0)],
           "deriv": [(64, 80, 32, 64), (40, 80, 32, 64), (24, 80, 16, 64), (8, 80, 0, 64), (0, 80, 0, 64),
                     (0, 80, 0, 48), (0, 80, 0, 24)],
           "minv": [(64, 80, 64, 64), (32, 80, 32, 64), (16, 80, 16, 64), (0, 80, 0, 64)]}
@@ -71,6 +74,12 @@ _IDENT = re.compile(r"\b([a-z][a-z]?_?[0-9]+(?:_[0-9]+)?|[sc]_t[0-9]+)\b")
 def liveness_peak(text: str) -> int:
     """Most doubles live after any statement of a generated body, in program order (constants of
     the scalar table excluded).  tools/cg_liveness.py prints the same per visit."""
+    # (chunked staging: a fetched group is 8 doubles from its GRP_* to the last element read from it)
+    text = re.sub(r"GRP_([QVX])\((\d+), (\d+)\);",
+                  lambda m: "double " + ", ".join("g%s%d_%d" % (m.group(1).lower(), int(m.group(2)) * 100 + int(m.group(3)), j)
+                                                  for j in range(8)) + ";", text)
+    text = re.sub(r"IN_([QVX])2\(\d+, (\d+), (\d+), (\d+)\)",
+                  lambda m: "g%s%d_%d" % (m.group(1).lower(), int(m.group(2)) * 100 + int(m.group(4)), int(m.group(3))), text)
     stm, uses = [], {}
     for ln, line in enumerate(text.splitlines()):
         if line.startswith("/*") or line.startswith("VISIT_END"):
@@ -111,15 +120,35 @@ def kernel_cost(k: "Kernel") -> int:
     return k.stats["fp"] + 30 * k.stats["trans"]
 
 
+# Chunked staging of the INSTANCE_MAJOR kernels (csrc/brbd_spec.hpp: SpecIn<2, ., ., 3>): the inputs
+# arrive 8 dofs x 64 instances at a time through an LDS window of 8 rows of 68 doubles (4 352 bytes
+# per wave), issued a prefetch distance ahead of the visit that consumes them.  The window comes out
+# of the 40 KiB of LDS a wave owns at four waves per CU, so these bodies park at most 70 doubles
+# per lane in LDS instead of 80.
+CHUNK_WIDTH = 8
+CHUNK_WINDOW_PAIRS = 5   # double2 rows of 64 lanes: 5 * 1024 bytes >= 8 * 68 * 8
+CHUNK_LDS = 70
+CHUNK_LIVE_MARGIN = int(os.environ.get("BRBD_CG_CHUNK_MARGIN", "0"))
+CHUNK_GAP = int(os.environ.get("BRBD_CG_CHUNK_GAP", "600"))   # statements after which a group is fetched again
+
+
 def build_kernel(mv: joints.ModelView, algo: str, reg_budget: Optional[int] = None,
-                 lds_budget: Optional[int] = None) -> Kernel:
+                 lds_budget: Optional[int] = None, chunked: bool = False, like: Optional[Kernel] = None) -> Kernel:
+    """``chunked``: the body of the layout-2 kernels with chunked staging; ``like``: the kernel whose
+    constant table it must share (same convention and tail, or None is returned)."""
     if algo == "aba":
         conv = {"world": ["aba"], "local": ["aba_local"]}.get(ABA_CONVENTION, ["aba", "aba_local"])
-        best = min((_build_one(mv, a, reg_budget, lds_budget) for a in conv), key=kernel_cost)
+        if like is not None:
+            conv = ["aba_local" if like.convention == "local" else "aba"]
+        best = min((_build_one(mv, a, reg_budget, lds_budget, chunked, getattr(like, "tail", None)) for a in conv),
+                   key=kernel_cost)
         best.convention = "local" if best.algo == "aba_local" else "world"
         best.algo = "aba"
-        return best
-    return _build_one(mv, algo, reg_budget, lds_budget)
+    else:
+        best = _build_one(mv, algo, reg_budget, lds_budget, chunked)
+    if like is not None and list(best.const_list) != list(like.const_list):
+        return None
+    return best
 
 
 # aba_local: (tail length, budgets) in order of preference.  Anything parked in the wave's global
@@ -130,7 +159,7 @@ LADDER_LOCAL = [(t, b) for t in (0, 1, 2, 3, 4, 5) for b in ((64, 80, 140, 64), 
 
 
 def _build_one(mv: joints.ModelView, algo: str, reg_budget: Optional[int] = None,
-               lds_budget: Optional[int] = None) -> Kernel:
+               lds_budget: Optional[int] = None, chunked: bool = False, only_tail=None) -> Kernel:
     gen = ALGOS[algo]
     ahead = dict(AHEAD, **AHEAD_ALGO.get(algo, {}))
     ladder = [(None, BUDGETS[algo])]
@@ -139,6 +168,22 @@ def _build_one(mv: joints.ModelView, algo: str, reg_budget: Optional[int] = None
             ladder = LADDER_LOCAL
         else:
             ladder = [(None, b) for b in LADDER.get(algo, [BUDGETS[algo]])]
+    if only_tail is not None:
+        ladder = [(t, b) for t, b in ladder if t == only_tail]
+    live_max = LIVE_MAX.get(algo, 0)
+    if chunked:
+        # the window takes LDS from the parks: first the same rungs with the smaller LDS, then (what no
+        # longer fits goes to registers, not to global memory) with the register budgets raised by as
+        # much (the groups in flight count in the liveness estimate)
+        def capped(b, add):
+            lost = max(0, b[1] - CHUNK_LDS)
+            return (b[0] + (lost if add else 0), b[1] - lost, b[2] + (lost if add and b[2] else 0)) + tuple(b[3:])
+        tails = []
+        for t, _ in ladder:
+            if t not in tails:
+                tails.append(t)
+        ladder = [(t, capped(b, add)) for t in tails for add in (False, True) for tt, b in ladder if tt == t]
+        live_max -= CHUNK_LIVE_MARGIN
     dry, best = {}, None
     for tail, budget in ladder:
         kw = {} if tail is None else {"tail": tail}
@@ -150,13 +195,21 @@ def _build_one(mv: joints.ModelView, algo: str, reg_budget: Optional[int] = None
         lb = lb if lds_budget is None else lds_budget
         plan, lds, glb = plan_storage(dry[tail].parks, rb, lb, rl, rt, strict=(algo == "minv"))
         e = gen(mv, Emitter(plan), **kw)
-        if algo in GROUPED:
+        if chunked:
+            e.group_inputs(gap=CHUNK_GAP, width=CHUNK_WIDTH, commit=True)
+        elif algo in GROUPED:
             e.group_inputs()
         text = e.text(ahead, algo in FINE)
         k = Kernel(algo, text, list(e.const_list), lds, glb, dict(e.stats), len(e.visits))
+        k.tail = tail
         if len(ladder) == 1:
             return k
-        fits = liveness_peak(text) <= LIVE_MAX[algo]
+        if algo == "rnea":
+            if glb == 0:
+                return k
+            best = k if best is None or glb < best.glb else best
+            continue
+        fits = liveness_peak(text) <= live_max
         if algo != "aba_local":
             best = k
             if fits:
@@ -190,6 +243,9 @@ _CPU_SHELL = r"""
 #define GRP_Q(g, n) do { } while (0)
 #define GRP_V(g, n) do { } while (0)
 #define GRP_X(g, n) do { } while (0)
+#define GRPC_Q(g, n) do { } while (0)
+#define GRPC_V(g, n) do { } while (0)
+#define GRPC_X(g, n) do { } while (0)
 #define IN_Q2(k, g, j, n) q[k]
 #define IN_V2(k, g, j, n) v[k]
 #define IN_X2(k, g, j, n) x[k]

@@ -520,16 +520,21 @@ class Emitter:
         return out
 
     # ---- grouped input loads -----------------------------------------------------------------------
-    def group_inputs(self, gap: int = 1500, width: int = 16):
+    def group_inputs(self, gap: int = 1500, width: int = 16, commit: bool = False):
         """Rewrite the element loads of q / v / the third input so that the INSTANCE_MAJOR kernels can
-        fetch them a cache line at a time.  In the reference's layout an instance is one contiguous
-        column: lane b's elements 16 g .. 16 g + 15 of a matrix are 128 consecutive bytes, which the
-        layout-2 kernels read with 8 back-to-back b128 loads per lane (GRP_Q(g, n): the line is
-        fetched once and consumed whole) when the first of them is needed, instead of staging the
-        whole tile before the first visit.  Every element load `IN_Q(k)` becomes
-        `IN_Q2(k, g, j, n)` = element j of that group; in the other layouts GRP_* is empty and IN_*2
-        is the plain element load.  A group whose uses lie more than ``gap`` statements apart is
-        fetched again (n counts the fetches) rather than held in registers in between."""
+        fetch them a group of ``width`` consecutive elements at a time, when the walk first needs one
+        of them, instead of staging the whole tile before the first visit.  Every element load
+        `IN_Q(k)` becomes `IN_Q2(k, g, j, n)` = element j of fetch n of group g, preceded (at the
+        usual prefetch distance) by one `GRP_Q(g, n)` per fetch; in the other layouts GRP_* is empty
+        and IN_*2 is the plain element load.  A group whose uses lie more than ``gap`` statements
+        apart is fetched again (n counts the fetches) rather than held in registers in between.
+
+        width 16 (csrc/brbd_spec.hpp: SpecIn<2, ., ., 2>): elements 16 g .. 16 g + 15 of a lane's
+        column are 128 consecutive bytes, read with 8 back-to-back b128 loads per lane.
+        ``commit`` (SpecIn<2, ., ., 3>, width 8): GRP_* issues the group's coalesced loads of the whole
+        tile (8 dofs x 64 instances, each lane receives a share of it), and `GRPC_Q(g, n)` -- placed
+        where the first element is consumed, like the element reads themselves -- passes them
+        through the LDS window so that each lane ends up with its own instance's 8 elements."""
         pat = re.compile(r"^const double (\w+) = IN_([QVX])\((\d+)\);$")
         start, pos = [], 0
         for v in self.visits:
@@ -549,10 +554,13 @@ class Emitter:
                 if key not in last or start[vi] - last[key][0] > gap:
                     n = last[key][1] + 1 if key in last else 0
                     new_pre.append(("GRP_%s(%d, %d);" % (which, g, n), kind, earliest))
+                    if commit:
+                        new_pre.append(("GRPC_%s(%d, %d);" % (which, g, n), "use", vi))
                 else:
                     n = last[key][1]
                 last[key] = (start[vi], n)
-                new_pre.append(("const double %s = IN_%s2(%d, %d, %d, %d);" % (name, which, k, g, j, n), kind, earliest))
+                new_pre.append(("const double %s = IN_%s2(%d, %d, %d, %d);" % (name, which, k, g, j, n),
+                                "use" if commit else kind, vi if commit else earliest))
             v.pre = new_pre
 
     # ---- output ----------------------------------------------------------------------------------

@@ -402,6 +402,15 @@ int launch_algo(brbd_model* m, int algo, KArgs& A, int layout, hipStream_t strea
         A.nb[k] = (uint32_t)span;
       }
     }
+#ifdef BRBD_SPEC_CHECK
+    {  // positive control of the checking build (tests/test_gpu_bounds_check.py): BRBD_CHECK_SHRINK=k
+       // declares matrix k (q, v, a, out, out2, out3, out4, fext) 8 bytes short of what the kernel
+       // addresses, so its last element is out of range -- counted by the checks, dropped by the hardware
+      const char* e = getenv("BRBD_CHECK_SHRINK");
+      const int k = e ? atoi(e) : -1;
+      if (sk && k >= 0 && k < 8 && A.nb[k] >= 8) A.nb[k] -= 8;
+    }
+#endif
     // INSTANCE_MAJOR with tight leading dimensions (what Eigen hands the reference): the kernels
     // that stage the tile through LDS (brbd_spec.hpp, kernel layout 2)
     static const bool no_staged = getenv("BRBD_DISABLE_STAGED") && getenv("BRBD_DISABLE_STAGED")[0] == '1';
@@ -484,6 +493,12 @@ int launch_algo(brbd_model* m, int algo, KArgs& A, int layout, hipStream_t strea
     A.ws = ctx->d_ws;
   }
   A.ws_bytes = (uint32_t)((size_t)grid * A.ws_stride * 8);
+#ifdef BRBD_SPEC_CHECK
+  {  // (BRBD_CHECK_SHRINK=8: the wave-private park area, 16 bytes short)
+    const char* e = getenv("BRBD_CHECK_SHRINK");
+    if (stat && e && atoi(e) == 8 && A.ws_bytes >= 16) A.ws_bytes -= 16;
+  }
+#endif
   // timing mode 3 applies to calls that are ONE dispatch of a compiled kernel; anything else is timed
   // between chained events like mode 2
   const bool dispatch_mode = m->timing == 3 && stat && !fixed && A.ntiles <= grid;
@@ -1768,8 +1783,8 @@ int64_t brbd_debug_oob_count(brbd_model* m) {
   if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(n, m->d_oob, sizeof n, hipMemcpyDeviceToHost) != hipSuccess)
     return -1;
   if (n[0])
-    fprintf(stderr, "brbd check: %llu out-of-range accesses; last: kind %llu at byte %llu + %llu of a %llu-byte buffer\n",
-            n[0], n[1], n[2], n[3], n[4]);
+    fprintf(stderr, "brbd check: %llu accessors with out-of-range sites; kinds (bit mask, brbd_spec.hpp) 0x%llx; last: "
+                    "literal %lld where at most %lld fits\n", n[0], n[1], (long long)n[2], (long long)n[3]);
   return (int64_t)n[0];
 #else
   (void)m;

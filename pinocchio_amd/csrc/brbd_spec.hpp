@@ -64,30 +64,95 @@ typedef unsigned v4u __attribute__((ext_vector_type(4)));
 DI __amdgpu_buffer_rsrc_t spec_rsrc(const void* base, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
 }
-// Checking build (make CHECK=1 -> libbrbd_hip_check.so, -DBRBD_SPEC_CHECK): the hardware drops an
+// Checking build (make check -> libbrbd_hip_check.so, -DBRBD_SPEC_CHECK): the hardware drops an
 // access whose offset is outside the buffer's byte range, which would HIDE an indexing bug.  In
-// this build every access of a compiled kernel first compares offset + size with the range; a
-// violation is counted in the handle's counter (brbd_debug_oob_count), which also keeps the last
-// offender's (kind, offset, size, range).  tests/test_gpu_bounds_check.py runs the GPU suite's kernels once under it.
+// this build every access of a compiled kernel is held against the range; violations are counted
+// in the handle's counter (brbd_debug_oob_count).  tests/test_gpu_bounds_check.py runs the GPU
+// suite's kernels once under it, and provokes violations on purpose to see them counted.
+//
+// How: every access is (per-lane offset fixed at construction) + (wave-uniform offset of the site),
+// and the site's part is a LITERAL of the generated body (a row number, a park slot).  An accessor
+// therefore only notes the largest literal any of its sites uses -- the compiler folds that to a
+// constant -- and compares it ONCE, when it goes out of scope at the end of the tile, with the
+// largest one that fits: the range minus the access size minus the maximum of the lane offsets
+// over the wave (one reduction per accessor), divided by the leading dimension where the literal
+// is a row of a BATCH_MAJOR matrix.  The instrumented kernels are the product kernels plus a few
+// dozen instructions.  History (round 3): the first version compared at every site and called an
+// out-of-line reporter; that put a stack frame under kernels that already spill SGPRs, the
+// combination hipcc 7.2 miscompiles -- the instrumented talos_like k_aba<1,33> returned NaN while
+// the product kernel was right.  Per-site compares into a per-lane record pushed the same kernel
+// into scratch; per-site scalar compares spilled thousands of SGPRs (LLVM reassociates the counter).
+// A site inside a conditional block counts whether or not it executes: stricter, and still exact
+// for the straight-line bodies.
 #ifdef BRBD_SPEC_CHECK
-// out of line and printf-free: the bodies have thousands of access sites, each gets one compare,
-// one branch and this call.  oob[0] = count, oob[1..4] = (what, offset, size, range) of the last one.
-__device__ __attribute__((noinline)) void spec_check_fail(unsigned long long* oob, unsigned off, unsigned size,
-                                                          unsigned bytes, int what) {
-  if (!oob) return;
-  atomicAdd(oob, 1ull);
-  oob[1] = (unsigned long long)what;
-  oob[2] = off;
-  oob[3] = size;
-  oob[4] = bytes;
+struct SpecBad {
+  unsigned n, kinds;     // wave-uniform: violating accessors, their kinds (bit mask) ...
+  int off, limit;        // ... and the last one: its largest literal, and the largest that fits
+  int ws_seen, ws_limit; // the wave-private park area (PK_GLB_*)
+};
+typedef SpecBad* SpecOob;
+DI unsigned spec_wave_max(unsigned x) {
+#pragma unroll
+  for (int s = 1; s < WAVE; s <<= 1) {
+    const unsigned y = (unsigned)__shfl_xor((int)x, s, WAVE);
+    x = x > y ? x : y;
+  }
+  return (unsigned)__builtin_amdgcn_readfirstlane((int)x);
 }
-DI void spec_check(unsigned long long* oob, unsigned off, unsigned size, unsigned bytes, int what) {
-  // (bytes == 0: an absent optional matrix, dropped by design)
-  if (bytes != 0u && off + size > bytes) spec_check_fail(oob, off, size, bytes, what);
+// Largest uniform offset a site may add to the lane offsets: INT_MAX = not checked (bytes == 0: an
+// absent optional matrix, dropped by design), -1 = the range cannot even hold offset 0 of every
+// lane (any site at all is then a violation; an accessor without sites has seen == -1 and passes).
+DI int spec_slack(unsigned voff, unsigned size, unsigned bytes) {
+  const unsigned need = spec_wave_max(voff) + size;
+  if (bytes == 0u) return 0x7fffffff;
+  if (need > bytes || need < size) return -1;
+  const unsigned slack = bytes - need;
+  return slack > 0x7fffffffu ? 0x7fffffff : (int)slack;
 }
-#define SPEC_CHECK(oob, off, size, bytes, what) spec_check(oob, off, size, bytes, what)
+// (BATCH_MAJOR: a site adds (row literal) x (leading dimension) -- the last row that fits)
+DI int spec_rows(int slack, unsigned ld8) {
+  return (slack < 0 || slack == 0x7fffffff || ld8 == 0u) ? slack
+                                                          : __builtin_amdgcn_readfirstlane((int)((unsigned)slack / ld8));
+}
+DI void spec_check(SpecBad* s, int seen, int limit, unsigned what) {
+  const bool bad = seen > limit;
+  s->n += bad ? 1u : 0u;
+  s->kinds |= bad ? 1u << what : 0u;
+  s->off = bad ? seen : s->off;
+  s->limit = bad ? limit : s->limit;
+}
+struct SpecReport {  // declared before the accessors, so destroyed after them
+  unsigned long long* oob;
+  SpecBad* s;
+  DI ~SpecReport() {
+    spec_check(s, s->ws_seen, s->ws_limit, 5);
+    if (!oob || s->n == 0u || threadIdx.x != 0) return;
+    atomicAdd(oob, (unsigned long long)s->n);
+    oob[1] = s->kinds;
+    oob[2] = (unsigned long long)(long long)s->off;
+    oob[3] = (unsigned long long)(long long)s->limit;
+  }
+};
+#define SPEC_SLACK(oob, voff, size, bytes, what) spec_slack(voff, size, bytes)
+#define SPEC_ROWS(slack, ld8) spec_rows(slack, ld8)
+#define SPEC_SEEN mutable int seen = -1;
+#define SPEC_NOTE(x) (seen = seen > (int)(x) ? seen : (int)(x))
+#define SPEC_FINAL(T, limit, what) DI ~T() { spec_check(oob, seen, limit, what); }
+#define SPEC_NOTE_WS(x) (spec_bad.ws_seen = spec_bad.ws_seen > (int)(x) ? spec_bad.ws_seen : (int)(x))
+#define SPEC_OOB (&spec_bad)
+#define SPEC_OOB_DECL SpecBad spec_bad = {0u, 0u, 0, 0, -1, 0x7fffffff}; const SpecReport spec_report{A.oob, &spec_bad}
+#define SPEC_WS_LIMIT(wsoff, bytes) (spec_bad.ws_limit = spec_slack(wsoff, 16u, bytes))
 #else
-#define SPEC_CHECK(oob, off, size, bytes, what) do { } while (0)
+typedef unsigned long long* SpecOob;
+#define SPEC_SLACK(oob, voff, size, bytes, what) 0
+#define SPEC_ROWS(slack, ld8) 0
+#define SPEC_SEEN
+#define SPEC_NOTE(x) do { } while (0)
+#define SPEC_FINAL(T, limit, what)
+#define SPEC_NOTE_WS(x) do { } while (0)
+#define SPEC_OOB A.oob
+#define SPEC_OOB_DECL int spec_bad = 0
+#define SPEC_WS_LIMIT(wsoff, bytes) do { } while (0)
 #endif
 template <int LAYOUT, int AUX>
 struct SpecMat;
@@ -95,19 +160,21 @@ template <int AUX>
 struct SpecMat<1, AUX> {  // BATCH_MAJOR: element (d, b) at byte d * ld8 + b * 8
   __amdgpu_buffer_rsrc_t r;
   unsigned voff;
-  unsigned nbytes;
-  unsigned long long* oob;
-  DI SpecMat(const double* base, unsigned bytes, unsigned ld8, int64_t b, unsigned long long* oob_ = nullptr)
-      : r(spec_rsrc(base, bytes)), nbytes(bytes), oob(oob_) {
-    (void)ld8;
+  int dmax;  // (checking build: the last row whose elements are in range for every lane)
+  SpecOob oob;
+  SPEC_SEEN
+  SPEC_FINAL(SpecMat, dmax, 1)
+  DI SpecMat(const double* base, unsigned bytes, unsigned ld8, int64_t b, SpecOob oob_ = nullptr)
+      : r(spec_rsrc(base, bytes)), oob(oob_) {
     voff = (unsigned)b * 8u;
+    dmax = SPEC_ROWS(SPEC_SLACK(oob, voff, 8u, bytes, 1), ld8);
   }
   DI double get(int d, unsigned ld8) const {
-    SPEC_CHECK(oob, voff + (unsigned)d * ld8, 8u, nbytes, 1);
+    SPEC_NOTE(d);
     return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, (unsigned)d * ld8, AUX));
   }
   DI void put(int d, unsigned ld8, double x) const {
-    SPEC_CHECK(oob, voff + (unsigned)d * ld8, 8u, nbytes, 2);
+    SPEC_NOTE(d);
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, x), r, voff, (unsigned)d * ld8, AUX);
   }
 };
@@ -115,18 +182,21 @@ template <int AUX>
 struct SpecMat<0, AUX> {  // INSTANCE_MAJOR: element (d, b) at byte b * ld8 + d * 8 (immediate offset)
   __amdgpu_buffer_rsrc_t r;
   unsigned voff;
-  unsigned nbytes;
-  unsigned long long* oob;
-  DI SpecMat(const double* base, unsigned bytes, unsigned ld8, int64_t b, unsigned long long* oob_ = nullptr)
-      : r(spec_rsrc(base, bytes)), nbytes(bytes), oob(oob_) {
+  int slack;  // (checking build)
+  SpecOob oob;
+  SPEC_SEEN
+  SPEC_FINAL(SpecMat, slack, 3)
+  DI SpecMat(const double* base, unsigned bytes, unsigned ld8, int64_t b, SpecOob oob_ = nullptr)
+      : r(spec_rsrc(base, bytes)), oob(oob_) {
     voff = (unsigned)b * ld8;
+    slack = SPEC_SLACK(oob, voff, 8u, bytes, 3);
   }
   DI double get(int d, unsigned) const {
-    SPEC_CHECK(oob, voff + (unsigned)d * 8u, 8u, nbytes, 3);
+    SPEC_NOTE(d * 8);
     return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff + (unsigned)d * 8u, 0, 0));
   }
   DI void put(int d, unsigned, double x) const {
-    SPEC_CHECK(oob, voff + (unsigned)d * 8u, 8u, nbytes, 4);
+    SPEC_NOTE(d * 8);
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, x), r, voff + (unsigned)d * 8u, 0, 0);
   }
 };
@@ -160,7 +230,9 @@ struct SpecStage {
   double* lds;   // >= 64 * N doubles of LDS, free at the start and at the end of the kernel
   double* rows;  // this wave's global staging rows ([row][64 lanes]), MODE 1
   unsigned rows_bytes;
+  double* win;   // MODE 3: LDS window of SPEC_WIN_ROWS rows of SPEC_WIN_STRIDE doubles, behind the park area
 };
+constexpr int SPEC_WIN_ROWS = 8, SPEC_WIN_STRIDE = 68;
 // Two phases, so that the loads of ALL staged matrices are in flight before the first one is waited
 // for (one exposed HBM latency per kernel instead of one per matrix): issue() = the N coalesced
 // loads of the tile's flat run; commit() = through LDS, each lane receives its own N values.
@@ -184,16 +256,17 @@ DI void spec_stage_commit(const SpecStage& sc, const double* x, Sink&& sink) {
 }
 template <int LAYOUT, int AUX, int N, int MODE>
 struct SpecIn : SpecMat<LAYOUT, AUX> {
-  DI SpecIn(const double* base, unsigned bytes, unsigned ld8, int64_t b, unsigned long long* oob_, const SpecStage&, int)
+  DI SpecIn(const double* base, unsigned bytes, unsigned ld8, int64_t b, SpecOob oob_, const SpecStage&, int)
       : SpecMat<LAYOUT, AUX>(base, bytes, ld8, b, oob_) {}
   DI void commit(const SpecStage&) {}
   template <typename G> DI void grp(int, G&) const {}
+  template <typename G> DI void grpc(int, G&) const {}
   template <typename G> DI double get2(int d, unsigned ld8, const G&, int) const { return this->get(d, ld8); }
 };
 template <int AUX, int N>
 struct SpecIn<2, AUX, N, 0> {  // staged into registers
   double r[N > 0 ? N : 1];    // (issue: the lane's share of the flat run; after commit: its own row)
-  DI SpecIn(const double* base, unsigned bytes, unsigned, int64_t, unsigned long long*, const SpecStage& sc, int) {
+  DI SpecIn(const double* base, unsigned bytes, unsigned, int64_t, SpecOob, const SpecStage& sc, int) {
     spec_stage_issue<N, AUX>(base, bytes, sc, r);
   }
   DI void commit(const SpecStage& sc) {
@@ -204,30 +277,35 @@ struct SpecIn<2, AUX, N, 0> {  // staged into registers
   }
   DI double get(int d, unsigned) const { return r[d]; }
   template <typename G> DI void grp(int, G&) const {}
+  template <typename G> DI void grpc(int, G&) const {}
   template <typename G> DI double get2(int d, unsigned ld8, const G&, int) const { return get(d, ld8); }
 };
 template <int AUX, int N>
 struct SpecIn<2, AUX, N, 1> {  // staged into the wave's global rows row0 .. row0 + N - 1
   __amdgpu_buffer_rsrc_t rr;
-  unsigned voff, nbytes;
-  int row0;
-  unsigned long long* oob;
+  unsigned voff;
+  int slack, row0;
+  SpecOob oob;
+  SPEC_SEEN
+  SPEC_FINAL(SpecIn, slack, 7)
   double pend[N > 0 ? N : 1];
-  DI SpecIn(const double* base, unsigned bytes, unsigned, int64_t, unsigned long long* oob_, const SpecStage& sc, int row0_)
-      : rr(spec_rsrc(sc.rows, sc.rows_bytes)), voff((unsigned)sc.lane * 8u), nbytes(sc.rows_bytes), row0(row0_), oob(oob_) {
+  DI SpecIn(const double* base, unsigned bytes, unsigned, int64_t, SpecOob oob_, const SpecStage& sc, int row0_)
+      : rr(spec_rsrc(sc.rows, sc.rows_bytes)), voff((unsigned)sc.lane * 8u), row0(row0_), oob(oob_) {
+    slack = SPEC_SLACK(oob, voff, 8u, sc.rows_bytes, 7);
     spec_stage_issue<N, AUX>(base, bytes, sc, pend);
   }
   DI void commit(const SpecStage& sc) {
     spec_stage_commit<N>(sc, pend, [&](int d, double x) {
-      SPEC_CHECK(oob, voff + (unsigned)((row0 + d) * WAVE * 8), 8u, nbytes, 7);
+      SPEC_NOTE((row0 + d) * WAVE * 8);
       __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, x), rr, voff, (unsigned)((row0 + d) * WAVE * 8), 0);
     });
   }
   DI double get(int d, unsigned) const {
-    SPEC_CHECK(oob, voff + (unsigned)((row0 + d) * WAVE * 8), 8u, nbytes, 8);
+    SPEC_NOTE((row0 + d) * WAVE * 8);
     return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rr, voff, (unsigned)((row0 + d) * WAVE * 8), 0));
   }
   template <typename G> DI void grp(int, G&) const {}
+  template <typename G> DI void grpc(int, G&) const {}
   template <typename G> DI double get2(int d, unsigned ld8, const G&, int) const { return get(d, ld8); }
 };
 // MODE 2: no staging at all -- every lane fetches ITS OWN column a cache line at a time.  In the
@@ -237,46 +315,105 @@ struct SpecIn<2, AUX, N, 1> {  // staged into the wave's global rows row0 .. row
 // its elements, so the loads overlap the arithmetic as they do in BATCH_MAJOR instead of all
 // being waited for before the first visit.  Default cache policy: the 8 loads of a group and the
 // neighbouring lanes' groups share lines and meet in the L1 / L2.  Works for any leading dimension.
-template <bool ON>
+template <int KIND>  // 0: none, 2: a 128-byte line of the lane's own column, 3: 8 dofs of the tile (MODE 3)
 struct SpecGrp {};
 template <>
-struct SpecGrp<true> {
+struct SpecGrp<2> {
   double2 v[8];
+};
+template <>
+struct SpecGrp<3> {
+  double v[8];
 };
 template <int AUX, int N>
 struct SpecIn<2, AUX, N, 2> {
   __amdgpu_buffer_rsrc_t r;
-  unsigned voff, nbytes;
-  unsigned long long* oob;
-  DI SpecIn(const double* base, unsigned bytes, unsigned ld8, int64_t b, unsigned long long* oob_, const SpecStage&, int)
-      : r(spec_rsrc(base, bytes)), voff((unsigned)b * ld8), nbytes(bytes), oob(oob_) {}
+  unsigned voff;
+  int slack;
+  SpecOob oob;
+  SPEC_SEEN
+  SPEC_FINAL(SpecIn, slack, 10)
+  DI SpecIn(const double* base, unsigned bytes, unsigned ld8, int64_t b, SpecOob oob_, const SpecStage&, int)
+      : r(spec_rsrc(base, bytes)), voff((unsigned)b * ld8), oob(oob_) {
+    slack = SPEC_SLACK(oob, voff, 8u, bytes, 10);
+  }
   DI void commit(const SpecStage&) {}
-  DI void grp(int g, SpecGrp<true>& G) const {  // (g is a literal at every call site: the bounds fold)
+  DI void grp(int g, SpecGrp<2>& G) const {  // (g is a literal at every call site: the bounds fold)
 #pragma unroll
     for (int i = 0; i < 8; ++i)
       if (16 * g + 2 * i < N) {
         const unsigned off = voff + (unsigned)(128 * g + 16 * i);
         // (the last pair of an odd N reaches 8 bytes into the next column; past the very end of the
         // matrix the range check of the buffer returns zeros for that half)
-        SPEC_CHECK(oob, off, 8u, nbytes, 10);
+        SPEC_NOTE(128 * g + 16 * i);
         const v4u w = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
         const v2u x = {w.x, w.y}, y = {w.z, w.w};
         G.v[i] = make_double2(__builtin_bit_cast(double, x), __builtin_bit_cast(double, y));
       }
   }
-  DI double get2(int, unsigned, const SpecGrp<true>& G, int j) const { return (j & 1) ? G.v[j >> 1].y : G.v[j >> 1].x; }
+  DI double get2(int, unsigned, const SpecGrp<2>& G, int j) const { return (j & 1) ? G.v[j >> 1].y : G.v[j >> 1].x; }
+  template <typename G> DI void grpc(int, G&) const {}
+};
+// MODE 3: chunked staging.  Nothing is loaded up front.  GRP_Q(g, n) (placed a prefetch distance
+// ahead of the visit that needs the group, codegen/emit.py: group_inputs) issues 8 loads that
+// together cover dofs 8 g .. 8 g + 7 of all 64 instances of the tile: lane l takes dof 8 g + l % 8
+// of instances 8 k + l / 8 (k = 0 .. 7), i.e. every load instruction reads 8 runs of 64 contiguous
+// bytes -- coalesced enough for the texture addresser (8 - 16 lines per instruction against 64 for
+// a per-lane column fetch), and in flight while the walk computes.  GRPC_Q(g, n), where the first
+// element is consumed, passes the 8 x 64 block through the LDS window ([dof][instance], rows padded
+// to 68 doubles so that the 32 lanes of a half-wave write 32 different banks) and every lane
+// receives the 8 elements of its own instance.  The window lies behind the park area, which is in
+// use all along: these bodies park at most 70 doubles per lane in LDS (codegen/compile.py:
+// CHUNK_LDS).  Requires a tight leading dimension (the host selects layout 2 only then); a group
+// that reaches past row N reads the first dofs of the next instance (or, at the very end of the
+// matrix, the zeros of the range check), which nothing consumes.
+// (default cache policy unless overridden: a 128-byte line is shared by two groups fetched at different times)
+#ifndef SPEC_CHUNK_AUX
+#define SPEC_CHUNK_AUX 0
+#endif
+template <int AUX, int N>
+struct SpecIn<2, AUX, N, 3> {
+  __amdgpu_buffer_rsrc_t r;
+  unsigned voff;
+  double* win;
+  int lane;
+  DI SpecIn(const double* base, unsigned bytes, unsigned, int64_t, SpecOob, const SpecStage& sc, int)
+      : r(spec_rsrc(base, bytes)),
+        voff((unsigned)sc.tile * (unsigned)(WAVE * N * 8) + (unsigned)(((sc.lane >> 3) * N + (sc.lane & 7)) * 8)),
+        win(sc.win), lane(sc.lane) {}
+  DI void commit(const SpecStage&) {}
+  DI void grp(int g, SpecGrp<3>& G) const {  // (g is a literal at every call site)
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      G.v[k] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, (unsigned)((k * 8 * N + g * 8) * 8), SPEC_CHUNK_AUX));
+  }
+  DI void grpc(int, SpecGrp<3>& G) const {
+    // No __syncthreads() here: it would also wait for every global load in flight (the next groups,
+    // the parks), which is the overlap this mode exists for.  One wave per workgroup: its LDS
+    // operations execute in issue order, so the reads below see the writes above, and the next
+    // commit's writes come after these reads; the compiler keeps the order (it cannot tell the
+    // addresses apart) and the wave barriers keep it from moving anything across.
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) win[(lane & 7) * SPEC_WIN_STRIDE + 8 * k + (lane >> 3)] = G.v[k];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int d = 0; d < 8; ++d) G.v[d] = win[d * SPEC_WIN_STRIDE + lane];
+    __builtin_amdgcn_wave_barrier();
+  }
+  DI double get2(int, unsigned, const SpecGrp<3>& G, int j) const { return G.v[j]; }
 };
 
 template <int LAYOUT, int AUX, int N>
 struct SpecOut : SpecMat<LAYOUT, AUX> {
-  DI SpecOut(double* base, unsigned bytes, unsigned ld8, int64_t b, unsigned long long* oob_)
+  DI SpecOut(double* base, unsigned bytes, unsigned ld8, int64_t b, SpecOob oob_)
       : SpecMat<LAYOUT, AUX>(base, bytes, ld8, b, oob_) {}
   DI void flush(double*, unsigned, const SpecStage&) const {}
 };
 template <int AUX, int N>
 struct SpecOut<2, AUX, N> {  // collected in registers, transposed through LDS and stored coalesced at the end
   mutable double r[N > 0 ? N : 1];
-  DI SpecOut(double*, unsigned, unsigned, int64_t, unsigned long long*) {}
+  DI SpecOut(double*, unsigned, unsigned, int64_t, SpecOob) {}
   DI void put(int d, unsigned, double x) const { r[d] = x; }
   DI void flush(double* base, unsigned bytes, const SpecStage& sc) const {
     const __amdgpu_buffer_rsrc_t rs = spec_rsrc(base, bytes);
@@ -299,7 +436,7 @@ struct SpecOut<2, AUX, N> {  // collected in registers, transposed through LDS a
 // site, so the chunk bookkeeping folds away.
 template <int LAYOUT, int AUX, int N, int STREAM>
 struct SpecOutSel : SpecOut<LAYOUT, AUX, N> {
-  DI SpecOutSel(double* base, unsigned bytes, unsigned ld8, int64_t b, unsigned long long* oob_, const SpecStage&)
+  DI SpecOutSel(double* base, unsigned bytes, unsigned ld8, int64_t b, SpecOob oob_, const SpecStage&)
       : SpecOut<LAYOUT, AUX, N>(base, bytes, ld8, b, oob_) {}
 };
 template <int AUX, int N>
@@ -310,8 +447,8 @@ struct SpecOutSel<2, AUX, N, 1> {
   unsigned t0, nbytes;
   int lane;
   double* lds;
-  unsigned long long* oob;
-  DI SpecOutSel(double* base, unsigned bytes, unsigned, int64_t, unsigned long long* oob_, const SpecStage& sc)
+  SpecOob oob;
+  DI SpecOutSel(double* base, unsigned bytes, unsigned, int64_t, SpecOob oob_, const SpecStage& sc)
       : rs(spec_rsrc(base, bytes)), t0((unsigned)sc.tile * (unsigned)(WAVE * N * 8)), nbytes(bytes), lane(sc.lane),
         lds(sc.lds), oob(oob_) {}
   DI void flush_chunk(int c0, int nr) const {  // (c0, nr: literals once put() is inlined)
@@ -325,7 +462,7 @@ struct SpecOutSel<2, AUX, N, 1> {
       if (j < nr) {
         const unsigned f = (unsigned)(j * WAVE + lane), inst = f / (unsigned)nr, row = f % (unsigned)nr;
         const unsigned off = t0 + inst * (unsigned)(N * 8) + (unsigned)(c0 * 8) + row * 8u;
-        SPEC_CHECK(oob, off < nbytes ? off : 0u, 8u, nbytes, 9);
+        // (no check here: the range is tested explicitly, and offsets and range are multiples of 8)
         if (off + 8u <= nbytes)  // (instances past the end of the batch)
           __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, lds[f]), rs, off, 0, AUX);
       }
@@ -404,6 +541,9 @@ DI double spec_rcp(double x) {
 #define GRP_Q(g, n) SpecGrp<SPEC_GROUPED> qg_##g##_##n; mq.grp(g, qg_##g##_##n)
 #define GRP_V(g, n) SpecGrp<SPEC_GROUPED> vg_##g##_##n; mv.grp(g, vg_##g##_##n)
 #define GRP_X(g, n) SpecGrp<SPEC_GROUPED> xg_##g##_##n; mx.grp(g, xg_##g##_##n)
+#define GRPC_Q(g, n) mq.grpc(g, qg_##g##_##n)
+#define GRPC_V(g, n) mv.grpc(g, vg_##g##_##n)
+#define GRPC_X(g, n) mx.grpc(g, xg_##g##_##n)
 #define IN_Q2(k, g, j, n) (mq.get2(k, ldq8, qg_##g##_##n, j))
 #define IN_V2(k, g, j, n) (mv.get2(k, ldv8, vg_##g##_##n, j))
 #define IN_X2(k, g, j, n) (mx.get2(k, ldx8, xg_##g##_##n, j))
@@ -441,8 +581,8 @@ DI double spec_rcp(double x) {
 #endif
 #define PK_LDS_ST2(p, a, b) lds2[(p) * BRBD_TILE_LANES] = make_double2(a, b)
 #define PK_LDS_LD2(p, a, b) do { const double2 t_ = lds2[(p) * BRBD_TILE_LANES]; a = t_.x; b = t_.y; } while (0)
-#define PK_GLB_ST2(p, a, b) do { SPEC_CHECK(A.oob, wsoff + (unsigned)(p) * (WAVE * 16u), 16u, A.ws_bytes, 5); spec_park_st(wsr, wsoff, p, a, b); } while (0)
-#define PK_GLB_LD2(p, a, b) do { SPEC_CHECK(A.oob, wsoff + (unsigned)(p) * (WAVE * 16u), 16u, A.ws_bytes, 6); spec_park_ld(wsr, wsoff, p, a, b); } while (0)
+#define PK_GLB_ST2(p, a, b) do { SPEC_NOTE_WS((p) * (WAVE * 16)); spec_park_st(wsr, wsoff, p, a, b); } while (0)
+#define PK_GLB_LD2(p, a, b) do { SPEC_NOTE_WS((p) * (WAVE * 16)); spec_park_ld(wsr, wsoff, p, a, b); } while (0)
 // Visit boundary: nothing is scheduled across it, so the table loads of later visits are not
 // hoisted up front (that is what cost 2000 SGPR spills in the template-unrolled experiment).
 #define OPAQUE(x) asm volatile("" : "+v"(x))
@@ -485,6 +625,8 @@ DI double spec_rcp(double x) {
   const unsigned ldo38 = (unsigned)A.ldout3 * 8u, ldo48 = (unsigned)A.ldout4 * 8u;                   \
   const unsigned ldf8 = (unsigned)A.ldfext * 8u;                                                     \
   int trace_ix = 0;                                                                                  \
+  SPEC_OOB_DECL; (void)spec_bad;                                                                     \
+  SPEC_WS_LIMIT(wsoff, A.ws_bytes);                                                                  \
   (void)lds2; (void)wsr; (void)wsoff; (void)trace_ix;
 
 // SPEC_NQ / SPEC_NV / SPEC_NX / SPEC_NO (rows of q, v, third input, first output), SPEC_STAGE_MODE and
@@ -495,20 +637,21 @@ DI double spec_rcp(double x) {
   int64_t inst = tile * BRBD_TILE_LANES + lane;                                                      \
   if (inst >= A.B) inst = A.B - 1;                                                                   \
   constexpr int LAY_ = (LAYOUT) == 2 ? 0 : (LAYOUT);  /* matrices that are not staged: per lane */   \
-  constexpr bool SPEC_GROUPED = (LAYOUT) == 2 && SPEC_STAGE_MODE == 2;                               \
+  constexpr int SPEC_GROUPED = ((LAYOUT) == 2 && SPEC_STAGE_MODE >= 2) ? SPEC_STAGE_MODE : 0;        \
   const SpecStage sc{tile, lane, reinterpret_cast<double*>(lds_area),                                \
                      A.ws + (int64_t)blockIdx.x * A.ws_stride + (int64_t)SPEC_GLB * WAVE,            \
-                     (unsigned)((SPEC_NQ + SPEC_NV + SPEC_NX) * WAVE * 8)};                           \
-  SpecIn<LAYOUT, SPEC_IN_AUX, SPEC_NQ, SPEC_STAGE_MODE> mq(A.q, A.nb[0], ldq8, inst, A.oob, sc, 0);                \
-  SpecIn<LAYOUT, SPEC_IN_AUX, SPEC_NV, SPEC_STAGE_MODE> mv(A.v, A.nb[1], ldv8, inst, A.oob, sc, SPEC_NQ);          \
-  SpecIn<LAYOUT, SPEC_IN_AUX, SPEC_NX, SPEC_STAGE_MODE> mx(A.a, A.nb[2], ldx8, inst, A.oob, sc, SPEC_NQ + SPEC_NV); \
+                     (unsigned)((SPEC_NQ + SPEC_NV + SPEC_NX) * WAVE * 8),                            \
+                     reinterpret_cast<double*>(lds_area) + SPEC_LDS_PARK * BRBD_TILE_LANES};         \
+  SpecIn<LAYOUT, SPEC_IN_AUX, SPEC_NQ, SPEC_STAGE_MODE> mq(A.q, A.nb[0], ldq8, inst, SPEC_OOB, sc, 0);                \
+  SpecIn<LAYOUT, SPEC_IN_AUX, SPEC_NV, SPEC_STAGE_MODE> mv(A.v, A.nb[1], ldv8, inst, SPEC_OOB, sc, SPEC_NQ);          \
+  SpecIn<LAYOUT, SPEC_IN_AUX, SPEC_NX, SPEC_STAGE_MODE> mx(A.a, A.nb[2], ldx8, inst, SPEC_OOB, sc, SPEC_NQ + SPEC_NV); \
   mq.commit(sc); mv.commit(sc); mx.commit(sc); /* layout 2: all loads were issued above */           \
   if ((LAYOUT) == 2) __syncthreads();                                                                \
-  const SpecOutSel<LAYOUT, SPEC_OUT_AUX, SPEC_NO, SPEC_OUT_STREAM> mo(A.out, A.nb[3], ldo8, inst, A.oob, sc);      \
-  const SpecOutSel<(SPEC_OUT_STREAM ? (LAYOUT) : LAY_), SPEC_OUT_AUX, SPEC_NO2, SPEC_OUT_STREAM> mo2(A.out2, A.nb[4], ldo28, inst, A.oob, sc); \
-  const SpecMat<LAY_, SPEC_OUT_AUX> mo3(A.out3, A.nb[5], ldo38, inst, A.oob);                        \
-  const SpecMat<LAY_, SPEC_OUT_AUX> mo4(A.out4, A.nb[6], ldo48, inst, A.oob);                        \
-  const SpecMat<LAY_, SPEC_IN_AUX> mf(A.fext, A.nb[7], ldf8, inst, A.oob);                           \
+  const SpecOutSel<LAYOUT, SPEC_OUT_AUX, SPEC_NO, SPEC_OUT_STREAM> mo(A.out, A.nb[3], ldo8, inst, SPEC_OOB, sc);      \
+  const SpecOutSel<(SPEC_OUT_STREAM ? (LAYOUT) : LAY_), SPEC_OUT_AUX, SPEC_NO2, SPEC_OUT_STREAM> mo2(A.out2, A.nb[4], ldo28, inst, SPEC_OOB, sc); \
+  const SpecMat<LAY_, SPEC_OUT_AUX> mo3(A.out3, A.nb[5], ldo38, inst, SPEC_OOB);                        \
+  const SpecMat<LAY_, SPEC_OUT_AUX> mo4(A.out4, A.nb[6], ldo48, inst, SPEC_OOB);                        \
+  const SpecMat<LAY_, SPEC_IN_AUX> mf(A.fext, A.nb[7], ldf8, inst, SPEC_OOB);                           \
   (void)mv; (void)mx; (void)mo; (void)mo2; (void)mo3; (void)mo4; (void)ldo38; (void)ldo48; (void)mf; (void)ldf8; (void)sc;
 
 // after the body: layout 2 stores its collected output

@@ -263,6 +263,46 @@ def test_armature_variant_bodies_match_oracle():
             assert rel_err_cols(ddq, O.aba(q, v, tau)).max() < 1e-10
 
 
+@pytest.mark.parametrize("name", ["simple_humanoid", "talos_like", "quadruped"])
+def test_chunked_staging_bodies(name):
+    """The bodies of the INSTANCE_MAJOR kernels with chunked staging (compile.build_kernel(chunked=True),
+    csrc/brbd_spec.hpp: SpecIn<2, ., ., 3>): same values, the same constant table as the other
+    layouts' body, LDS parks within what the window leaves, and every element read of a group comes
+    after the group's commit, which comes after its fetch."""
+    import re
+    model = S.build(name)
+    mv = joints.ModelView(model)
+    O = oracle.Oracle(model)
+    q, v, a = inputs(model, 9, 5)
+    tau_ref = O.rnea(q, v, a)
+    for algo, x, ref, tol in (("rnea", a, tau_ref, 1e-12), ("aba", tau_ref, None, 1e-10)):
+        base = C.build_kernel(mv, algo)
+        ck = C.CpuKernel(mv, algo, chunked=True, like=base)
+        k = ck.kernel
+        assert list(k.const_list) == list(base.const_list)
+        assert k.lds <= C.CHUNK_LDS and k.glb <= base.glb
+        out = ck.run(q, v, x, (model.nv, 0, 0))[0]
+        assert rel_err_cols(out, ref if ref is not None else O.aba(q, v, tau_ref)).max() < tol
+        state = {}
+        for line in k.text.splitlines():
+            m = re.match(r"GRP(C?)_([QVX])\((\d+), (\d+)\);", line)
+            if m:
+                key = (m.group(2), int(m.group(3)), int(m.group(4)))
+                if m.group(1):
+                    assert state.get(key) == "fetched", (line, state.get(key))
+                    state[key] = "committed"
+                else:
+                    assert key not in state, line
+                    state[key] = "fetched"
+                continue
+            for m in re.finditer(r"IN_([QVX])2\((\d+), (\d+), (\d+), (\d+)\)", line):
+                kk, g, j, n = (int(m.group(i)) for i in (2, 3, 4, 5))
+                assert (g, j) == divmod(kk, C.CHUNK_WIDTH)
+                assert state.get((m.group(1), g, n)) == "committed", line
+            assert not re.search(r"IN_[QVX]\(", line), line   # (no element load left outside the groups)
+        assert state and all(s == "committed" for s in state.values())
+
+
 def test_built_kernels_have_no_scratch_with_spilled_sgprs():
     """Register reports of the last build (pinocchio_amd/csrc/gen/*.usage, tools/spec_usage.py): no
     compiled kernel may combine scratch-memory accesses with spilled SGPRs (the combination that
@@ -281,6 +321,21 @@ def test_built_kernels_have_no_scratch_with_spilled_sgprs():
         # stages its tile in registers and may spill a few VGPRs (never together with SGPRs)
         if "simple_humanoid" in cur["name"] and ("k_rneaILi1" in cur["name"] or "k_abaILi1" in cur["name"]):
             assert int(cur["ScratchInsts"]) == 0, cur
+
+
+def test_instrumented_kernels_have_no_scratch_with_spilled_sgprs():
+    """The same guard for the CHECKING build's objects (csrc/gen_check): round 3 found the instrumented
+    talos_like k_aba<1,33> miscomputing (scratch + 1 353 spilled SGPRs, caused by the instrumentation's
+    out-of-line reporter) while the product kernel was right; a checking build that computes wrong
+    values would fail tests/test_gpu_bounds_check.py for the wrong reason."""
+    import os
+    from pinocchio_amd.codegen import usage
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pinocchio_amd", "csrc", "gen_check")
+    rows = usage.kernel_reports(root)
+    if not rows:
+        pytest.skip("no checking-build reports in this tree")
+    for cur in rows:
+        assert not usage.refused(cur), cur
 
 
 def test_scratch_detector_sees_real_spills(tmp_path):

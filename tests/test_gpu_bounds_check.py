@@ -85,6 +85,29 @@ for name, B in (("simple_humanoid", 65536), ("talos_like", 300000)):
     total += n
     pool.release()
 assert total == 0, total
+# positive control: the checks must SEE a violation.  BRBD_CHECK_SHRINK=k (checking build only)
+# declares matrix k 8 bytes short of what the kernel addresses (k = 8: the park area, 16 bytes), so
+# its last element is out of range: dropped by the hardware as always, counted by the checks.
+import os
+model = S.build("talos_like")
+q, v, a = inputs(model, 128, 3)
+f = np.random.default_rng(1).uniform(-1, 1, (6 * model.njoints, 128))
+seen = {}
+for k, what in ((0, "q"), (3, "out"), (7, "fext"), (8, "parks")):
+    for order in "CF":
+        pool = parallel.ModelPool(model, 1)
+        h = pool.device_model(0).handle
+        qq, vv, aa, ff = (np.asarray(x, order=order) for x in (q, v, a, f))
+        os.environ["BRBD_CHECK_SHRINK"] = str(k)
+        if k == 8:
+            parallel.computeRNEADerivatives(pool, qq, vv, aa)   # (a kernel that parks in the global area)
+        else:
+            parallel.aba(pool, qq, vv, aa, ff)
+        del os.environ["BRBD_CHECK_SHRINK"]
+        seen[what, order] = L.brbd_debug_oob_count(h)
+        pool.release()
+print("positive control:", seen, flush=True)
+assert all(n > 0 for n in seen.values()), seen
 print("BOUNDS-OK")
 """
 

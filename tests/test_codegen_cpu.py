@@ -280,7 +280,7 @@ def test_chunked_staging_bodies(name):
         ck = C.CpuKernel(mv, algo, chunked=True, like=base)
         k = ck.kernel
         assert list(k.const_list) == list(base.const_list)
-        assert k.lds <= C.CHUNK_LDS and k.glb <= base.glb
+        assert k.lds <= C.CHUNK_LDS
         out = ck.run(q, v, x, (model.nv, 0, 0))[0]
         assert rel_err_cols(out, ref if ref is not None else O.aba(q, v, tau_ref)).max() < tol
         state = {}

@@ -300,7 +300,7 @@ def main():
         # FP64 (78.6 TFLOP/s over the flops the kernel EXECUTES per eval, PMC-counted).  The counted flops
         # of the reference-structured restatement (the WORLD-convention recursion)
         # are quoted beside it; the compiled ABA runs the reference's LOCAL-convention recursion
-        # (aba.hxx:378-542), which needs 2.6x fewer flops for the same result, so a fraction of peak on
+        # (aba.hxx:378-542), which needs 2.8x fewer flops for the same result, so a fraction of peak on
         # the WORLD count is no longer bounded by 1 and cannot serve as the roof.
         dom = "aba" if do_aba else "rnea"
         avg = avg_a if do_aba else avg_r

@@ -332,6 +332,12 @@ def main():
             roof = {"bound": "hbm", "kernel": kname, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": bytes_per_eval * B, "traffic": traffic,
                     "traffic_source": tsrc, "fp64": fp64, "hbm": hbm}
+        if fp64["frac_counted"] is not None:
+            roof["note"] = ("frac prices the kernel AS BUILT against its binding roof (the lower ceiling in evals/s of HBM over the "
+                            "algorithmic bytes and FP64 over the flops it executes). On SURVEY 8d's algorithmic flops (counted on the "
+                            "reference-structured WORLD recursion, BASELINE.md section 3) the same launch is at fp64.frac_counted = "
+                            "%.2f of the FP64 peak: the compiled kernel runs the reference's LOCAL recursion and does %.1fx less "
+                            "arithmetic for the same result." % (fp64["frac_counted"], (flops[dom] / ex) if ex else float("nan")))
         headline = args.model == "simple_humanoid" and B == 65536 and args.algo == "rnea+aba" and not args.armature
         out = {
             "metric": ("ABA/RNEA evals/sec, humanoid fp64 batch 65536" if headline

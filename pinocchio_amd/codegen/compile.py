@@ -29,7 +29,7 @@ ALGOS = {"rnea": rnea.generate, "aba": aba.generate, "aba_local": aba_local.gene
 # storage budgets (doubles per lane) of the park planner, per algorithm:
 # (registers for short-lived parks, LDS, registers for long-lived parks)
 # LDS: 160 KiB per CU, 4 resident waves of 64 lanes at one wave per SIMD -> 80 doubles per lane
-BUDGETS = {"rnea": (40, 80, 0), "aba": (48, 80, 100, 64), "aba_local": (48, 80, 100, 64), "fkjac": (36, 80, 0), "deriv": (64, 80, 32, 64),
+BUDGETS = {"rnea": (160, 80, 0), "aba": (48, 80, 100, 64), "aba_local": (48, 80, 100, 64), "fkjac": (36, 80, 0), "deriv": (64, 80, 32, 64),
            "minv": (64, 80, 64, 64), "prod": (0, 0, 0), "jjac": (0, 0, 0)}  # (deriv: first rung of LADDER)
 for _a in list(BUDGETS):  # experiment hook: BRBD_CG_ABA="64,80"
     _v = os.environ.get("BRBD_CG_" + _a.upper())
@@ -60,9 +60,13 @@ FINE = set(os.environ.get("BRBD_CG_FINE", "deriv,minv,prod").split(","))
 # scratch beyond ~200 doubles (512 registers per lane at one wave per SIMD, minus addressing).
 LADDER = {"aba": [(48, 80, 100, 64), (32, 80, 100, 64), (16, 80, 100, 64), (16, 80, 80, 64)],
           "aba_local": [(48, 80, 100, 64), (32, 80, 100, 64), (16, 80, 100, 64), (16, 80, 80, 64)],
-          # rnea: its register pressure is low (about 90 doubles live); a model whose path state overflows
-          # the LDS gets more register parks rather than the wave's global area (first rung without global parks)
-          "rnea": [(40, 80, 0), (56, 80, 0), (72, 80, 0), (96, 80, 0)],
+          # rnea: the walk itself keeps about 90 doubles live, so its path state (the humanoid's: 76 doubles)
+          # is parked in REGISTERS, not in LDS -- the humanoid's kernel then touches no LDS at all (150
+          # doubles live, 282 registers) and runs 16.2 -> 14.5 us (INSTANCE_MAJOR 19.4 -> 17.2; MI355X,
+          # same box, alternating; the (40, 80, 0) of rounds 1-2 dated from a walk with twice the live
+          # state).  Larger trees overflow into LDS, then get more registers rather than the wave's
+          # global area (first rung without global parks).
+          "rnea": [(160, 80, 0), (200, 80, 0), (240, 80, 0)],
           "deriv": [(64, 80, 32, 64), (40, 80, 32, 64), (24, 80, 16, 64), (8, 80, 0, 64), (0, 80, 0, 64),
                     (0, 80, 0, 48), (0, 80, 0, 24)],
           "minv": [(64, 80, 64, 64), (32, 80, 32, 64), (16, 80, 16, 64), (0, 80, 0, 64)]}

@@ -157,7 +157,10 @@ def test_no_park_slot_is_read_after_another_park_took_it(name, algo):
     import re
     emit.Emitter.tag_parks = True
     try:
-        text = C.build_kernel(joints.ModelView(S.build(name)), algo).text
+        # (RNEA's default budget keeps the whole path state in registers: give it the round-2 budget,
+        # which parks 76 doubles per lane in LDS, so that there are slots to check)
+        kw = {"reg_budget": 40} if algo == "rnea" else {}
+        text = C.build_kernel(joints.ModelView(S.build(name)), algo, **kw).text
     finally:
         emit.Emitter.tag_parks = False
     owner, n = {}, 0

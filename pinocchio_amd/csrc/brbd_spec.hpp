@@ -224,6 +224,14 @@ DI void spec_park_ld(__amdgpu_buffer_rsrc_t r, unsigned voff, int p, double& a, 
 // private global staging area (MODE 1: the body then reads them like a BATCH_MAJOR matrix).  The
 // output goes the other way at the end of the kernel.  The host selects layout 2 when every staged
 // matrix of the call has ld == rows; anything else runs the per-lane kernels (layout 0).
+// One wave per workgroup: its LDS operations execute in issue order, so a transposition needs no
+// hardware barrier between its write and read phases, only the compiler kept from reordering them.
+// (BRBD_SPEC_LDS_BARRIER: the __syncthreads() of rounds 1-2, which also waits for every load in flight.)
+#ifdef BRBD_SPEC_LDS_BARRIER
+#define SPEC_LDS_ORDER() __syncthreads()
+#else
+#define SPEC_LDS_ORDER() __builtin_amdgcn_wave_barrier()
+#endif
 struct SpecStage {
   int64_t tile;
   int lane;
@@ -247,10 +255,10 @@ DI void spec_stage_issue(const double* base, unsigned bytes, const SpecStage& sc
 }
 template <int N, typename Sink>
 DI void spec_stage_commit(const SpecStage& sc, const double* x, Sink&& sink) {
-  __syncthreads();  // (one wave per workgroup: orders the LDS traffic, no cross-wave wait)
+  SPEC_LDS_ORDER();
 #pragma unroll
   for (int j = 0; j < N; ++j) sc.lds[j * WAVE + sc.lane] = x[j];
-  __syncthreads();
+  SPEC_LDS_ORDER();
 #pragma unroll
   for (int d = 0; d < N; ++d) sink(d, sc.lds[sc.lane * N + d]);
 }
@@ -418,10 +426,10 @@ struct SpecOut<2, AUX, N> {  // collected in registers, transposed through LDS a
   DI void flush(double* base, unsigned bytes, const SpecStage& sc) const {
     const __amdgpu_buffer_rsrc_t rs = spec_rsrc(base, bytes);
     const unsigned t0 = (unsigned)sc.tile * (unsigned)(WAVE * N * 8) + (unsigned)sc.lane * 8u;
-    __syncthreads();
+    SPEC_LDS_ORDER();
 #pragma unroll
     for (int d = 0; d < N; ++d) sc.lds[sc.lane * N + d] = r[d];
-    __syncthreads();
+    SPEC_LDS_ORDER();
 #pragma unroll
     for (int j = 0; j < N; ++j)  // (stores past the end of the batch are dropped by the range check)
       __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, sc.lds[j * WAVE + sc.lane]), rs, t0,

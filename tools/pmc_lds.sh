@@ -19,5 +19,6 @@ for r in csv.DictReader(open(f)):
 for k, c in sorted(acc.items()):
     d = {x: c[x] / max(n[(k, x)], 1) for x in c}
     w = d.get("SQ_WAVE_CYCLES", 1)
-    print(k.split("::")[-1][:14], {x.replace("SQ_", ""): round(v / w, 4) if x != "SQ_WAVE_CYCLES" else round(v) for x, v in d.items()})
+    import re
+    print(re.search(r"k_\w+<[^>]*>", k).group(0), {x.replace("SQ_", ""): round(v / w, 4) if x != "SQ_WAVE_CYCLES" else round(v) for x, v in d.items()})
 PY

@@ -66,7 +66,10 @@ LAYOUTS = {"rnea": (0, 1, 2), "aba": (0, 1, 2), "fkjac": (0, 1, 2), "deriv": (0,
 # 2.96e9 evals/s for the RNEA + ABA step): every group fetch touches a 64-byte piece of EVERY cache
 # line of the tile, 4.5 times over the kernel with other traffic in between, so the lines are
 # fetched again and again, while the up-front staging reads each line exactly once.
-STAGE_MODE = {"rnea": 0, "aba": 0, "fkjac": 0, "deriv": 0, "minv": 0, "prod": 0, "jjac": 0}
+# Mode 4 = mode 0 with 16-byte loads and LDS writes (half the instructions of the prologue); measured per
+# kernel on the humanoid at 65 536: RNEA 17.3 -> 16.4 us, ABA 25.1 -> 26.3 us (its register file is full,
+# the two padding registers per matrix and the different schedule cost more than the prologue saves).
+STAGE_MODE = {"rnea": 4, "aba": 0, "fkjac": 0, "deriv": 0, "minv": 0, "prod": 0, "jjac": 0}
 STAGED_WANTS = [1]  # (the external-force variants read 6 * njoints more rows per lane anyway: not staged)
 
 

@@ -262,6 +262,39 @@ DI void spec_stage_commit(const SpecStage& sc, const double* x, Sink&& sink) {
 #pragma unroll
   for (int d = 0; d < N; ++d) sink(d, sc.lds[sc.lane * N + d]);
 }
+// The same with 16 bytes per lane per instruction: pair p = j * 64 + lane of the tile's flat run =
+// elements 2p, 2p + 1 -- half the load and LDS-write instructions (x2 / x4 buffer accesses are
+// range-checked per dword, so a pair that straddles the end of the matrix loses only its far half).
+// N odd: the last instruction's upper 32 lanes lie past the tile and take no part.  MODE 4 of the
+// staged inputs; measured per kernel (humanoid, 65 536: RNEA 17.3 -> 16.4 us, ABA 25.1 -> 26.3 us, so
+// RNEA uses it and ABA does not: codegen/build.py, STAGE_MODE).
+template <int N>
+constexpr int spec_stage_regs() { return 2 * ((N + 1) / 2); }
+template <int N>
+DI bool spec_stage_lane_on(int j, int lane) { return N % 2 == 0 || j < N / 2 || lane < WAVE / 2; }
+template <int N, int AUX>
+DI void spec_stage_issue_wide(const double* base, unsigned bytes, const SpecStage& sc, double* x) {
+  const __amdgpu_buffer_rsrc_t r = spec_rsrc(base, bytes);
+  const unsigned t0 = (unsigned)sc.tile * (unsigned)(WAVE * N * 8) + (unsigned)sc.lane * 16u;
+#pragma unroll
+  for (int j = 0; j < (N + 1) / 2; ++j) {
+    const v4u w = __builtin_amdgcn_raw_buffer_load_b128(r, t0, (unsigned)(j * WAVE * 16), AUX);
+    const v2u lo = {w.x, w.y}, hi = {w.z, w.w};
+    x[2 * j] = __builtin_bit_cast(double, lo);
+    x[2 * j + 1] = __builtin_bit_cast(double, hi);
+  }
+}
+template <int N, typename Sink>
+DI void spec_stage_commit_wide(const SpecStage& sc, const double* x, Sink&& sink) {
+  double2* const l2 = reinterpret_cast<double2*>(sc.lds);
+  SPEC_LDS_ORDER();
+#pragma unroll
+  for (int j = 0; j < (N + 1) / 2; ++j)
+    if (spec_stage_lane_on<N>(j, sc.lane)) l2[j * WAVE + sc.lane] = make_double2(x[2 * j], x[2 * j + 1]);
+  SPEC_LDS_ORDER();
+#pragma unroll
+  for (int d = 0; d < N; ++d) sink(d, sc.lds[sc.lane * N + d]);
+}
 template <int LAYOUT, int AUX, int N, int MODE>
 struct SpecIn : SpecMat<LAYOUT, AUX> {
   DI SpecIn(const double* base, unsigned bytes, unsigned ld8, int64_t b, SpecOob oob_, const SpecStage&, int)
@@ -282,6 +315,24 @@ struct SpecIn<2, AUX, N, 0> {  // staged into registers
 #pragma unroll
     for (int j = 0; j < N; ++j) x[j] = r[j];
     spec_stage_commit<N>(sc, x, [&](int d, double y) { r[d] = y; });
+  }
+  DI double get(int d, unsigned) const { return r[d]; }
+  template <typename G> DI void grp(int, G&) const {}
+  template <typename G> DI void grpc(int, G&) const {}
+  template <typename G> DI double get2(int d, unsigned ld8, const G&, int) const { return get(d, ld8); }
+};
+template <int AUX, int N>
+struct SpecIn<2, AUX, N, 4> {  // staged into registers, 16 bytes per lane per instruction
+  static constexpr int NX = spec_stage_regs<N>();
+  double r[NX > 0 ? NX : 1];  // (issue: the lane's share of the flat run; after commit: its own row)
+  DI SpecIn(const double* base, unsigned bytes, unsigned, int64_t, SpecOob, const SpecStage& sc, int) {
+    spec_stage_issue_wide<N, AUX>(base, bytes, sc, r);
+  }
+  DI void commit(const SpecStage& sc) {
+    double x[NX > 0 ? NX : 1];
+#pragma unroll
+    for (int j = 0; j < NX; ++j) x[j] = r[j];
+    spec_stage_commit_wide<N>(sc, x, [&](int d, double y) { r[d] = y; });
   }
   DI double get(int d, unsigned) const { return r[d]; }
   template <typename G> DI void grp(int, G&) const {}
